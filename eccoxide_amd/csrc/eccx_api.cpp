@@ -1,0 +1,350 @@
+// C ABI of the engine (include/eccx.h): contexts, buffers, comb-table construction and
+// kernel launches.  No arithmetic happens on the host: the comb tables are produced by
+// the engine's own variable-base kernel at first use (each entry (j+1)*16^i*G is the
+// generator times a scalar with a single non-zero nibble), which stands in for the
+// reference's generated constants (src/params/comb/<curve>.rs, sage/comb.sage) and its
+// build_comb_table (src/curve/projective.rs:451-472, src/curve/curve25519.rs:881-902).
+#include "../../include/eccx.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "launch.hpp"
+
+namespace {
+
+using eccx::CurveOps;
+
+constexpr int NCURVES = 5;
+// internal kernel option bits (kernels.hpp)
+constexpr uint32_t K_BASE_IS_GENERATOR = 1u << 0;
+constexpr uint32_t K_OUT_TABLE = 1u << 1;
+constexpr uint32_t K_VALIDATE = 1u << 2;
+
+const CurveOps* ops_of(int curve) {
+  switch (curve) {
+    case ECCX_P256R1: return &eccx::ops_P256();
+    case ECCX_P384R1: return &eccx::ops_P384();
+    case ECCX_P521R1: return &eccx::ops_P521();
+    case ECCX_BLS12_381_G1: return &eccx::ops_BLS12_381();
+    case ECCX_ED25519: return &eccx::ops_ED25519();
+    default: return nullptr;
+  }
+}
+
+}  // namespace
+
+struct eccx_ctx {
+  int device = 0;
+  int cus = 0;
+  hipStream_t stream = nullptr;
+  uint32_t* comb[NCURVES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  std::mutex comb_mu;
+  uint32_t* scratch = nullptr;
+  size_t scratch_words = 0;
+  std::mutex scratch_mu;
+  std::string err;
+};
+
+namespace {
+
+#define HIP_TRY(ctx, call)                                                                     \
+  do {                                                                                         \
+    hipError_t e_ = (call);                                                                    \
+    if (e_ != hipSuccess) {                                                                    \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                          \
+      return e_ == hipErrorOutOfMemory ? ECCX_ERR_NOMEM : ECCX_ERR_HIP;                        \
+    }                                                                                          \
+  } while (0)
+
+// Persistent grid: the variable-base kernel keeps a 16-row window table per lane in a
+// scratch slab indexed by workgroup, so the grid is capped at a few workgroups per CU
+// and each workgroup strides over the batch.
+int grid_for(const eccx_ctx* ctx, size_t n) {
+  size_t need = (n + eccx::LAUNCH_WG - 1) / eccx::LAUNCH_WG;
+  size_t cap = (size_t)ctx->cus * 4;
+  return (int)std::max<size_t>(1, std::min(need, cap));
+}
+
+int ensure_scratch(eccx_ctx* ctx, const CurveOps* ops, int grid) {
+  size_t words = (size_t)grid * 16 * eccx::LAUNCH_WG * (size_t)ops->info.row_words;
+  std::lock_guard<std::mutex> g(ctx->scratch_mu);
+  if (words <= ctx->scratch_words) return ECCX_OK;
+  if (ctx->scratch) {
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, hipFree(ctx->scratch));
+    ctx->scratch = nullptr;
+    ctx->scratch_words = 0;
+  }
+  HIP_TRY(ctx, hipMalloc(&ctx->scratch, words * sizeof(uint32_t)));
+  ctx->scratch_words = words;
+  return ECCX_OK;
+}
+
+int launch_var(eccx_ctx* ctx, const CurveOps* ops, size_t n, const uint8_t* d_scalars, const uint8_t* d_points,
+               uint8_t* d_out, uint8_t* d_flags, uint8_t* d_proj, uint32_t kopts, hipStream_t s) {
+  if (n == 0) return ECCX_OK;
+  int grid = grid_for(ctx, n);
+  if (ops->info.row_words) {
+    int rc = ensure_scratch(ctx, ops, grid);
+    if (rc) return rc;
+  }
+  HIP_TRY(ctx, ops->var(grid, s, n, d_scalars, d_points, d_out, d_flags, d_proj, ctx->scratch, kopts));
+  return ECCX_OK;
+}
+
+// scalars with one non-zero nibble: row w*16+d encodes d * 16^w (big-endian, SB bytes)
+std::vector<uint8_t> comb_scalars(const CurveOps* ops) {
+  int sb = ops->info.sb, nw = 2 * sb;
+  std::vector<uint8_t> k((size_t)nw * 16 * sb, 0);
+  for (int w = 0; w < nw; ++w)
+    for (int d = 0; d < 16; ++d) {
+      uint8_t* row = k.data() + ((size_t)w * 16 + d) * sb;
+      row[sb - 1 - w / 2] = (uint8_t)((w & 1) ? (d << 4) : d);
+    }
+  return k;
+}
+
+int ensure_comb(eccx_ctx* ctx, int curve, const CurveOps* ops) {
+  std::lock_guard<std::mutex> g(ctx->comb_mu);
+  if (ctx->comb[curve]) return ECCX_OK;
+  int nw = 2 * ops->info.sb;
+  size_t rows = (size_t)nw * 16;
+  std::vector<uint8_t> k = comb_scalars(ops);
+  uint8_t* d_k = nullptr;
+  uint32_t* d_tab = nullptr;
+  HIP_TRY(ctx, hipMalloc(&d_k, k.size()));
+  HIP_TRY(ctx, hipMalloc(&d_tab, rows * ops->info.table_words * sizeof(uint32_t)));
+  HIP_TRY(ctx, hipMemcpyAsync(d_k, k.data(), k.size(), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemsetAsync(d_tab, 0, rows * ops->info.table_words * sizeof(uint32_t), ctx->stream));
+  int rc = launch_var(ctx, ops, rows, d_k, nullptr, reinterpret_cast<uint8_t*>(d_tab), nullptr, nullptr,
+                      K_BASE_IS_GENERATOR | K_OUT_TABLE, ctx->stream);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipFree(d_k));
+  ctx->comb[curve] = d_tab;
+  return ECCX_OK;
+}
+
+uint32_t kopts_of(uint32_t opts) { return (opts & ECCX_VALIDATE_POINTS) ? K_VALIDATE : 0u; }
+
+size_t proj_bytes(const CurveOps* ops) { return (size_t)(ops->info.edwards ? 4 : 3) * ops->info.fb; }
+
+// host-buffer wrapper shared by var / base
+int run_host(eccx_ctx* ctx, int curve, bool base, size_t n, const uint8_t* scalars, const uint8_t* points,
+             uint8_t* out, uint8_t* flags, uint8_t* proj, uint32_t opts) {
+  const CurveOps* ops = ops_of(curve);
+  if (!ctx) return ECCX_ERR_ARG;
+  if (!ops) return ECCX_ERR_CURVE;
+  if (n == 0) return ECCX_OK;
+  if (!scalars || !out || !flags || (!base && !points)) return ECCX_ERR_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  size_t sb = ops->info.sb, pb = 2 * (size_t)ops->info.fb;
+  uint8_t *d_k = nullptr, *d_p = nullptr, *d_o = nullptr, *d_f = nullptr, *d_j = nullptr;
+  int rc = ECCX_OK;
+  auto cleanup = [&]() {
+    if (d_k) (void)hipFree(d_k);
+    if (d_p) (void)hipFree(d_p);
+    if (d_o) (void)hipFree(d_o);
+    if (d_f) (void)hipFree(d_f);
+    if (d_j) (void)hipFree(d_j);
+  };
+#define TRY_(call)                                  \
+  do {                                              \
+    hipError_t e_ = (call);                         \
+    if (e_ != hipSuccess) {                         \
+      ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); \
+      cleanup();                                    \
+      return e_ == hipErrorOutOfMemory ? ECCX_ERR_NOMEM : ECCX_ERR_HIP; \
+    }                                               \
+  } while (0)
+  TRY_(hipMalloc(&d_k, n * sb));
+  TRY_(hipMalloc(&d_o, n * pb));
+  TRY_(hipMalloc(&d_f, n));
+  if (!base) TRY_(hipMalloc(&d_p, n * pb));
+  if (proj) TRY_(hipMalloc(&d_j, n * proj_bytes(ops)));
+  TRY_(hipMemcpyAsync(d_k, scalars, n * sb, hipMemcpyHostToDevice, ctx->stream));
+  if (!base) TRY_(hipMemcpyAsync(d_p, points, n * pb, hipMemcpyHostToDevice, ctx->stream));
+  if (base) rc = eccx_scalarmul_base_dev(ctx, curve, n, d_k, d_o, d_f, d_j, opts, ctx->stream);
+  else rc = eccx_scalarmul_var_dev(ctx, curve, n, d_k, d_p, d_o, d_f, d_j, opts, ctx->stream);
+  if (rc) { cleanup(); return rc; }
+  TRY_(hipMemcpyAsync(out, d_o, n * pb, hipMemcpyDeviceToHost, ctx->stream));
+  TRY_(hipMemcpyAsync(flags, d_f, n, hipMemcpyDeviceToHost, ctx->stream));
+  if (proj) TRY_(hipMemcpyAsync(proj, d_j, n * proj_bytes(ops), hipMemcpyDeviceToHost, ctx->stream));
+  TRY_(hipStreamSynchronize(ctx->stream));
+#undef TRY_
+  cleanup();
+  return ECCX_OK;
+}
+
+int run_sharded(eccx_ctx** ctxs, int nctx, int curve, bool base, size_t n, const uint8_t* scalars,
+                const uint8_t* points, uint8_t* out, uint8_t* flags, uint32_t opts) {
+  const CurveOps* ops = ops_of(curve);
+  if (!ops) return ECCX_ERR_CURVE;
+  if (!ctxs || nctx < 1) return ECCX_ERR_ARG;
+  for (int i = 0; i < nctx; ++i)
+    if (!ctxs[i]) return ECCX_ERR_ARG;
+  size_t sb = ops->info.sb, pb = 2 * (size_t)ops->info.fb;
+  std::vector<int> rcs((size_t)nctx, ECCX_OK);
+  std::vector<std::thread> th;
+  for (int g = 0; g < nctx; ++g) {
+    size_t lo = n * (size_t)g / (size_t)nctx, hi = n * (size_t)(g + 1) / (size_t)nctx;  // contiguous shards
+    th.emplace_back([=, &rcs]() {
+      rcs[(size_t)g] = run_host(ctxs[g], curve, base, hi - lo, scalars + lo * sb, base ? nullptr : points + lo * pb,
+                                out + lo * pb, flags + lo, nullptr, opts);
+    });
+  }
+  for (auto& t : th) t.join();
+  for (int rc : rcs)
+    if (rc) return rc;
+  return ECCX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int eccx_field_bytes(int curve) {
+  const CurveOps* o = ops_of(curve);
+  return o ? o->info.fb : ECCX_ERR_CURVE;
+}
+int eccx_scalar_bytes(int curve) {
+  const CurveOps* o = ops_of(curve);
+  return o ? o->info.sb : ECCX_ERR_CURVE;
+}
+
+int eccx_init(int device, eccx_ctx** out_ctx) {
+  if (!out_ctx) return ECCX_ERR_ARG;
+  *out_ctx = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return ECCX_ERR_HIP;
+  if (hipSetDevice(device) != hipSuccess) return ECCX_ERR_HIP;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return ECCX_ERR_HIP;
+  eccx_ctx* ctx = new (std::nothrow) eccx_ctx();
+  if (!ctx) return ECCX_ERR_NOMEM;
+  ctx->device = device;
+  ctx->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return ECCX_ERR_HIP;
+  }
+  *out_ctx = ctx;
+  return ECCX_OK;
+}
+
+void eccx_shutdown(eccx_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (auto& t : ctx->comb)
+    if (t) (void)hipFree(t);
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* eccx_last_error(const eccx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+const char* eccx_strerror(int code) {
+  switch (code) {
+    case ECCX_OK: return "ok";
+    case ECCX_ERR_CURVE: return "unknown curve id";
+    case ECCX_ERR_ARG: return "bad argument";
+    case ECCX_ERR_HIP: return "HIP runtime error";
+    case ECCX_ERR_NOMEM: return "out of device memory";
+    default: return "unknown error";
+  }
+}
+
+int eccx_scalarmul_var_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_scalars, const void* d_points,
+                           void* d_out, void* d_flags, void* d_proj, uint32_t opts, void* stream) {
+  const CurveOps* ops = ops_of(curve);
+  if (!ctx) return ECCX_ERR_ARG;
+  if (!ops) return ECCX_ERR_CURVE;
+  if (n == 0) return ECCX_OK;
+  if (!d_scalars || !d_points || !d_out || !d_flags) return ECCX_ERR_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+  return launch_var(ctx, ops, n, static_cast<const uint8_t*>(d_scalars), static_cast<const uint8_t*>(d_points),
+                    static_cast<uint8_t*>(d_out), static_cast<uint8_t*>(d_flags), static_cast<uint8_t*>(d_proj),
+                    kopts_of(opts), s);
+}
+
+int eccx_scalarmul_base_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_scalars, void* d_out, void* d_flags,
+                            void* d_proj, uint32_t opts, void* stream) {
+  const CurveOps* ops = ops_of(curve);
+  if (!ctx) return ECCX_ERR_ARG;
+  if (!ops) return ECCX_ERR_CURVE;
+  if (n == 0) return ECCX_OK;
+  if (!d_scalars || !d_out || !d_flags) return ECCX_ERR_ARG;
+  (void)opts;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_comb(ctx, curve, ops);
+  if (rc) return rc;
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+  size_t need = (n + eccx::LAUNCH_WG - 1) / eccx::LAUNCH_WG;
+  int grid = (int)std::max<size_t>(1, std::min(need, (size_t)ctx->cus * 8));
+  HIP_TRY(ctx, ops->base(grid, s, n, static_cast<const uint8_t*>(d_scalars), ctx->comb[curve],
+                         static_cast<uint8_t*>(d_out), static_cast<uint8_t*>(d_flags),
+                         static_cast<uint8_t*>(d_proj), 0u));
+  return ECCX_OK;
+}
+
+int eccx_scalarmul_var(eccx_ctx* ctx, int curve, size_t n, const uint8_t* scalars, const uint8_t* points,
+                       uint8_t* out, uint8_t* flags, uint8_t* proj, uint32_t opts) {
+  return run_host(ctx, curve, false, n, scalars, points, out, flags, proj, opts);
+}
+
+int eccx_scalarmul_base(eccx_ctx* ctx, int curve, size_t n, const uint8_t* scalars, uint8_t* out, uint8_t* flags,
+                        uint8_t* proj, uint32_t opts) {
+  return run_host(ctx, curve, true, n, scalars, nullptr, out, flags, proj, opts);
+}
+
+int eccx_comb_table(eccx_ctx* ctx, int curve, uint8_t* out) {
+  const CurveOps* ops = ops_of(curve);
+  if (!ctx || !out) return ECCX_ERR_ARG;
+  if (!ops) return ECCX_ERR_CURVE;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int nw = 2 * ops->info.sb;
+  size_t rows = (size_t)nw * 16, pb = 2 * (size_t)ops->info.fb;
+  std::vector<uint8_t> k = comb_scalars(ops);
+  std::vector<uint8_t> aff(rows * pb), fl(rows);
+  uint8_t *d_k = nullptr, *d_o = nullptr, *d_f = nullptr;
+  HIP_TRY(ctx, hipMalloc(&d_k, k.size()));
+  HIP_TRY(ctx, hipMalloc(&d_o, aff.size()));
+  HIP_TRY(ctx, hipMalloc(&d_f, rows));
+  HIP_TRY(ctx, hipMemcpyAsync(d_k, k.data(), k.size(), hipMemcpyHostToDevice, ctx->stream));
+  int rc = launch_var(ctx, ops, rows, d_k, nullptr, d_o, d_f, nullptr, K_BASE_IS_GENERATOR, ctx->stream);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(aff.data(), d_o, aff.size(), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  (void)hipFree(d_k);
+  (void)hipFree(d_o);
+  (void)hipFree(d_f);
+  for (int w = 0; w < nw; ++w)
+    for (int d = 1; d < 16; ++d)
+      std::memcpy(out + ((size_t)w * 15 + (size_t)(d - 1)) * pb, aff.data() + ((size_t)w * 16 + (size_t)d) * pb, pb);
+  return ECCX_OK;
+}
+
+int eccx_scalarmul_var_sharded(eccx_ctx** ctxs, int nctx, int curve, size_t n, const uint8_t* scalars,
+                               const uint8_t* points, uint8_t* out, uint8_t* flags, uint32_t opts) {
+  if (n && (!scalars || !points || !out || !flags)) return ECCX_ERR_ARG;
+  return run_sharded(ctxs, nctx, curve, false, n, scalars, points, out, flags, opts);
+}
+
+int eccx_scalarmul_base_sharded(eccx_ctx** ctxs, int nctx, int curve, size_t n, const uint8_t* scalars, uint8_t* out,
+                                uint8_t* flags, uint32_t opts) {
+  if (n && (!scalars || !out || !flags)) return ECCX_ERR_ARG;
+  return run_sharded(ctxs, nctx, curve, true, n, scalars, nullptr, out, flags, opts);
+}
+
+}  // extern "C"

@@ -1,0 +1,22 @@
+// Kernel instantiations for BLS12_381 (see kernels.hpp).
+#include "kernels.hpp"
+#include "launch.hpp"
+
+namespace eccx {
+namespace {
+hipError_t var_(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t* out,
+                uint8_t* flags, uint8_t* proj, uint32_t* scratch, uint32_t opts) {
+  hipLaunchKernelGGL(k_scalarmul_var<BLS12_381>, dim3(grid), dim3(WG), 0, s, n, scalars, points, out, flags, proj, scratch, opts);
+  return hipGetLastError();
+}
+hipError_t base_(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint32_t* table, uint8_t* out,
+                 uint8_t* flags, uint8_t* proj, uint32_t opts) {
+  hipLaunchKernelGGL(k_scalarmul_base<BLS12_381>, dim3(grid), dim3(WG), 0, s, n, scalars, table, out, flags, proj, opts);
+  return hipGetLastError();
+}
+}  // namespace
+const CurveOps& ops_BLS12_381() {
+  static const CurveOps o = {{BLS12_381::FB, BLS12_381::SB, BLS12_381::L, 2 * BLS12_381::L, row_words<BLS12_381::L>(), 0}, var_, base_};
+  return o;
+}
+}  // namespace eccx

@@ -1,0 +1,22 @@
+// Kernel instantiations for P256 (see kernels.hpp).
+#include "kernels.hpp"
+#include "launch.hpp"
+
+namespace eccx {
+namespace {
+hipError_t var_(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t* out,
+                uint8_t* flags, uint8_t* proj, uint32_t* scratch, uint32_t opts) {
+  hipLaunchKernelGGL(k_scalarmul_var<P256>, dim3(grid), dim3(WG), 0, s, n, scalars, points, out, flags, proj, scratch, opts);
+  return hipGetLastError();
+}
+hipError_t base_(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint32_t* table, uint8_t* out,
+                 uint8_t* flags, uint8_t* proj, uint32_t opts) {
+  hipLaunchKernelGGL(k_scalarmul_base<P256>, dim3(grid), dim3(WG), 0, s, n, scalars, table, out, flags, proj, opts);
+  return hipGetLastError();
+}
+}  // namespace
+const CurveOps& ops_P256() {
+  static const CurveOps o = {{P256::FB, P256::SB, P256::L, 2 * P256::L, row_words<P256::L>(), 0}, var_, base_};
+  return o;
+}
+}  // namespace eccx

@@ -1,0 +1,359 @@
+// Batched scalar-multiplication kernels for gfx950: one (scalar, base) pair per
+// lane, 256-thread workgroups (4 wavefronts), no cross-lane communication.
+//
+//   k_scalarmul_var<C>   &Point * &Scalar           curve_macros.rs:321-327 -> :47-49 / :103-105
+//                        -> scale_{am3,a0}_ct        projective.rs:905-918
+//                        -> scalar_mul_fixed_window  projective.rs:871-896 / :842-867
+//   k_scalarmul_base<C>  Point::mul_base             curve_macros.rs:55-63 / :111-119
+//                        -> mul_base_table_{am3,a0}  projective.rs:965-981 / :945-961
+//   k_ed_scalarmul_var   curve25519::Point::scale    curve25519.rs:746-762 (double-and-add)
+//   k_ed_scalarmul_base  curve25519::Point::mul_base curve25519.rs:840-851
+//   tails                to_affine_ct                projective.rs:655-682 ; curve25519.rs:663-666
+//
+// The per-lane 16-entry window table of the variable-base ladder (projective.rs:875-881)
+// does not fit LDS at a useful occupancy (16 x 96 B x 64 lanes = 96 KiB per wavefront
+// for P-256), so it lives in an HBM scratch slab, one row of W words per (entry, lane),
+// read back with 16-byte loads; it is private to the lane, so no synchronisation.
+// Lookups index the table directly: the reference scans all 16 entries for
+// constant-time behaviour (projective.rs:427-434), which changes timing, not values.
+//
+// The ladder is written as ONE loop whose body holds a single copy of the doubling
+// and a single copy of the addition (table build and main loop share them), chosen by
+// wave-uniform control flow, so the whole kernel stays inside the instruction cache.
+#pragma once
+#include "curve.hpp"
+
+namespace eccx {
+
+enum : uint32_t {
+  OPT_BASE_IS_GENERATOR = 1u << 0,  // ignore `points`, use the curve generator
+  OPT_OUT_TABLE = 1u << 1,          // write affine Montgomery limbs (comb-table rows) instead of bytes
+  OPT_VALIDATE = 1u << 2,           // reject non-canonical / off-curve input points (flag 2)
+};
+
+constexpr int WG = 256;
+
+template <int L>
+constexpr int row_words() { return ((3 * L + 3) / 4) * 4; }  // padded to 16 bytes
+
+template <class C>
+ECCX_DEV void row_store(uint32_t* __restrict__ row, const Pt<C>& p) {
+  constexpr int L = C::L;
+  uint32_t w[row_words<L>()];
+#pragma unroll
+  for (int i = 0; i < L; ++i) { w[i] = p.x.v[i]; w[L + i] = p.y.v[i]; w[2 * L + i] = p.z.v[i]; }
+#pragma unroll
+  for (int i = 3 * L; i < row_words<L>(); ++i) w[i] = 0;
+  uint4* dst = reinterpret_cast<uint4*>(row);
+#pragma unroll
+  for (int i = 0; i < row_words<L>() / 4; ++i) dst[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+
+template <class C>
+ECCX_DEV void row_load(Pt<C>& p, const uint32_t* __restrict__ row) {
+  constexpr int L = C::L;
+  uint32_t w[row_words<L>()];
+  const uint4* src = reinterpret_cast<const uint4*>(row);
+#pragma unroll
+  for (int i = 0; i < row_words<L>() / 4; ++i) {
+    uint4 q = src[i];
+    w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
+  }
+#pragma unroll
+  for (int i = 0; i < L; ++i) { p.x.v[i] = w[i]; p.y.v[i] = w[L + i]; p.z.v[i] = w[2 * L + i]; }
+}
+
+// y^2 == x^3 + a x + b  (affine.rs:103-119), Montgomery inputs
+template <class C>
+ECCX_DEV bool on_curve(const Fe<C::L>& x, const Fe<C::L>& y) {
+  Fe<C::L> y2, x3, t, bb;
+  fe_sqr<C>(y2, y);
+  fe_sqr<C>(x3, x);
+  fe_mul<C>(x3, x3, x);
+  if constexpr (!C::A0) {  // a = -3
+    fe_add<C>(t, x, x);
+    fe_add<C>(t, t, x);
+    fe_sub<C>(x3, x3, t);
+  }
+  fe_set<C>(bb, C::B);
+  fe_add<C>(x3, x3, bb);
+  return fe_eq<C>(y2, x3);
+}
+
+// (X:Y:Z) -> affine x, y (Montgomery) ; returns false for the point at infinity
+template <class C>
+ECCX_DEV bool to_affine(Fe<C::L>& ax, Fe<C::L>& ay, const Pt<C>& q) {
+  bool present = !fe_is_zero<C>(q.z);
+  Fe<C::L> z, zi, one;
+  fe_set<C>(one, C::ONE);
+  fe_select<C>(z, present, q.z, one);  // z_inverse_ct: substitute 1 (projective.rs:655-659)
+  fe_inv<C>(zi, z);
+  fe_mul<C>(ax, q.x, zi);
+  fe_mul<C>(ay, q.y, zi);
+  return present;
+}
+
+// Common tail: write the result of one unit.
+//   out   : n x 2FB canonical big-endian x||y (zeros for infinity)      [or table rows]
+//   flags : n bytes, 0 = finite, 1 = infinity, 2 = rejected input
+//   proj  : optional n x 3FB canonical big-endian X||Y||Z, the reference's
+//           un-normalised result
+template <class C>
+ECCX_DEV void store_result(size_t idx, const Pt<C>& q, bool rejected, uint8_t* __restrict__ out,
+                           uint8_t* __restrict__ flags, uint8_t* __restrict__ proj, uint32_t opts) {
+  constexpr int L = C::L;
+  constexpr int FB = C::FB;
+  Fe<L> ax, ay, t;
+  bool present = to_affine<C>(ax, ay, q);
+  if (opts & OPT_OUT_TABLE) {
+    uint32_t* row = reinterpret_cast<uint32_t*>(out) + idx * (size_t)(2 * L);
+#pragma unroll
+    for (int i = 0; i < L; ++i) { row[i] = ax.v[i]; row[L + i] = ay.v[i]; }
+    return;
+  }
+  bool ok = present && !rejected;
+  fe_from_mont<C>(t, ax);
+  if (!ok) fe_zero<C>(t);
+  fe_store_be<C>(out + idx * (size_t)(2 * FB), t);
+  fe_from_mont<C>(t, ay);
+  if (!ok) fe_zero<C>(t);
+  fe_store_be<C>(out + idx * (size_t)(2 * FB) + FB, t);
+  flags[idx] = rejected ? 2 : (present ? 0 : 1);
+  if (proj) {
+    uint8_t* pr = proj + idx * (size_t)(3 * FB);
+    fe_from_mont<C>(t, q.x); fe_store_be<C>(pr, t);
+    fe_from_mont<C>(t, q.y); fe_store_be<C>(pr + FB, t);
+    fe_from_mont<C>(t, q.z); fe_store_be<C>(pr + 2 * FB, t);
+  }
+}
+
+template <class C>
+__global__ void __launch_bounds__(WG) k_scalarmul_var(size_t n, const uint8_t* __restrict__ scalars,
+                                                      const uint8_t* __restrict__ points, uint8_t* __restrict__ out,
+                                                      uint8_t* __restrict__ flags, uint8_t* __restrict__ proj,
+                                                      uint32_t* __restrict__ scratch, uint32_t opts) {
+  constexpr int L = C::L;
+  constexpr int FB = C::FB;
+  constexpr int SB = C::SB;
+  constexpr int W = row_words<L>();
+  // scratch slab of this lane, reused across the grid-stride loop:
+  // [workgroup][entry 0..15][thread 0..255][W words]
+  uint32_t* slab = scratch + ((size_t)blockIdx.x * 16 * WG + threadIdx.x) * (size_t)W;
+  auto row = [&](uint32_t e) { return slab + (size_t)e * WG * W; };
+  for (size_t base = (size_t)blockIdx.x * WG; base < n; base += (size_t)gridDim.x * WG) {
+  const size_t gid = base + threadIdx.x;
+  const bool active = gid < n;
+  const size_t idx = active ? gid : n - 1;  // idle lanes shadow the last unit, never store
+
+  Pt<C> q;
+  bool rejected = false;
+  if (opts & OPT_BASE_IS_GENERATOR) {
+    fe_set<C>(q.x, C::GX);
+    fe_set<C>(q.y, C::GY);
+  } else {
+    Fe<L> rx, ry;
+    fe_load_be<C>(rx, points + idx * (size_t)(2 * FB));
+    fe_load_be<C>(ry, points + idx * (size_t)(2 * FB) + FB);
+    fe_to_mont<C>(q.x, rx);
+    fe_to_mont<C>(q.y, ry);
+    if (opts & OPT_VALIDATE) {
+      rejected = !(fe_is_canonical<C>(rx) && fe_is_canonical<C>(ry) && on_curve<C>(q.x, q.y));
+    }
+  }
+  fe_set<C>(q.z, C::ONE);
+  {
+    Pt<C> inf;
+    pt_set_inf<C>(inf);
+    row_store<C>(row(0), inf);
+    row_store<C>(row(1), q);
+  }
+  const uint8_t* __restrict__ k = scalars + idx * (size_t)SB;
+
+  // steps 0..13 build table[2..15]; then NW windows of (4 doublings + 1 addition)
+  constexpr int NW = 2 * SB;
+  constexpr int NSTEPS = 14 + 5 * NW;
+  int win = 0, sub = 0;
+  for (int s = 0; s < NSTEPS; ++s) {
+    const bool building = s < 14;
+    bool do_dbl;
+    if (building) {
+      do_dbl = (s == 0);
+    } else {
+      if (s == 14) pt_set_inf<C>(q);
+      do_dbl = sub < 4;
+    }
+    if (do_dbl) {
+      pt_dbl<C>(q, q);
+    } else {
+      uint32_t e = 1;
+      if (!building) {
+        uint32_t byte = k[win >> 1];
+        e = (win & 1) ? (byte & 0x0f) : (byte >> 4);  // high nibble first (projective.rs:885)
+      }
+      Pt<C> sel;
+      row_load<C>(sel, row(e));
+      pt_add<C>(q, q, sel);
+    }
+    if (building) {
+      row_store<C>(row(s + 2), q);
+    } else {
+      if (++sub == 5) { sub = 0; ++win; }
+    }
+  }
+  if (active) store_result<C>(idx, q, rejected, out, flags, proj, opts);
+  }  // grid-stride
+}
+
+// Fixed-base comb: table[w][d] (d = 1..15) = d * 16^w * G as affine Montgomery limbs,
+// 2L words per entry, entry 0 of each window unused (digit 0 selects infinity).
+template <class C>
+__global__ void __launch_bounds__(WG) k_scalarmul_base(size_t n, const uint8_t* __restrict__ scalars,
+                                                       const uint32_t* __restrict__ table,
+                                                       uint8_t* __restrict__ out, uint8_t* __restrict__ flags,
+                                                       uint8_t* __restrict__ proj, uint32_t opts) {
+  constexpr int L = C::L;
+  constexpr int SB = C::SB;
+  constexpr int NW = 2 * SB;
+  for (size_t base = (size_t)blockIdx.x * WG; base < n; base += (size_t)gridDim.x * WG) {
+  const size_t gid = base + threadIdx.x;
+  const bool active = gid < n;
+  const size_t idx = active ? gid : n - 1;
+  const uint8_t* __restrict__ k = scalars + idx * (size_t)SB;
+  Pt<C> q;
+  pt_set_inf<C>(q);
+  for (int w = 0; w < NW; ++w) {
+    uint32_t byte = k[SB - 1 - (w >> 1)];
+    uint32_t d = (w & 1) ? (byte >> 4) : (byte & 0x0f);  // low nibble first (projective.rs:974-976)
+    Pt<C> sel;
+    const uint32_t* __restrict__ e = table + ((size_t)w * 16 + d) * (2 * L);
+#pragma unroll
+    for (int i = 0; i < L; ++i) { sel.x.v[i] = e[i]; sel.y.v[i] = e[L + i]; }
+    fe_set<C>(sel.z, C::ONE);
+    if (d == 0) pt_set_inf<C>(sel);
+    pt_add<C>(q, q, sel);
+  }
+  if (active) store_result<C>(idx, q, false, out, flags, proj, opts);
+  }  // grid-stride
+}
+
+// ---- edwards25519 -----------------------------------------------------------------
+// out: n x 64 affine x||y little-endian (curve25519.rs:138); flags: 1 = neutral element.
+// proj (optional): n x 128 little-endian X||Y||Z||T.
+template <class C>
+ECCX_DEV void ed_store_result(size_t idx, const EdPt<C>& q, bool rejected, uint8_t* __restrict__ out,
+                              uint8_t* __restrict__ flags, uint8_t* __restrict__ proj, uint32_t opts) {
+  constexpr int L = C::L;
+  Fe<L> zi, ax, ay, t, one;
+  fe_inv<C>(zi, q.z);  // Z != 0 on a complete Edwards curve (curve25519.rs:663-666)
+  fe_mul<C>(ax, q.x, zi);
+  fe_mul<C>(ay, q.y, zi);
+  if (opts & OPT_OUT_TABLE) {  // comb rows: x, y, t = x*y (from_affine, curve25519.rs:638-645)
+    uint32_t* row = reinterpret_cast<uint32_t*>(out) + idx * (size_t)(3 * L);
+    fe_mul<C>(t, ax, ay);
+#pragma unroll
+    for (int i = 0; i < L; ++i) { row[i] = ax.v[i]; row[L + i] = ay.v[i]; row[2 * L + i] = t.v[i]; }
+    return;
+  }
+  fe_set<C>(one, C::ONE);
+  bool neutral = fe_is_zero<C>(ax) && fe_eq<C>(ay, one);
+  fe_from_mont<C>(t, ax);
+  if (rejected) fe_zero<C>(t);
+  fe_store_le<C>(out + idx * 64, t);
+  fe_from_mont<C>(t, ay);
+  if (rejected) fe_zero<C>(t);
+  fe_store_le<C>(out + idx * 64 + 32, t);
+  flags[idx] = rejected ? 2 : (neutral ? 1 : 0);
+  if (proj) {
+    uint8_t* pr = proj + idx * 128;
+    fe_from_mont<C>(t, q.x); fe_store_le<C>(pr, t);
+    fe_from_mont<C>(t, q.y); fe_store_le<C>(pr + 32, t);
+    fe_from_mont<C>(t, q.z); fe_store_le<C>(pr + 64, t);
+    fe_from_mont<C>(t, q.t); fe_store_le<C>(pr + 96, t);
+  }
+}
+
+template <class C>
+__global__ void __launch_bounds__(WG) k_ed_scalarmul_var(size_t n, const uint8_t* __restrict__ scalars,
+                                                         const uint8_t* __restrict__ points,
+                                                         uint8_t* __restrict__ out, uint8_t* __restrict__ flags,
+                                                         uint8_t* __restrict__ proj, uint32_t opts) {
+  constexpr int L = C::L;
+  for (size_t base = (size_t)blockIdx.x * WG; base < n; base += (size_t)gridDim.x * WG) {
+  const size_t gid = base + threadIdx.x;
+  const bool active = gid < n;
+  const size_t idx = active ? gid : n - 1;
+  EdPt<C> p, q;
+  bool rejected = false;
+  if (opts & OPT_BASE_IS_GENERATOR) {
+    fe_set<C>(p.x, C::GX);
+    fe_set<C>(p.y, C::GY);
+  } else {
+    Fe<L> rx, ry;
+    fe_load_le<C>(rx, points + idx * 64);
+    fe_load_le<C>(ry, points + idx * 64 + 32);
+    fe_to_mont<C>(p.x, rx);
+    fe_to_mont<C>(p.y, ry);
+    if (opts & OPT_VALIDATE) {
+      // -x^2 + y^2 == 1 + d x^2 y^2  <=>  2(y^2 - x^2 - 1) == 2d x^2 y^2  (curve25519.rs:649-660)
+      Fe<L> xx, yy, lhs, rhs, one;
+      fe_sqr<C>(xx, p.x);
+      fe_sqr<C>(yy, p.y);
+      fe_set<C>(one, C::ONE);
+      fe_sub<C>(lhs, yy, xx);
+      fe_sub<C>(lhs, lhs, one);
+      fe_add<C>(lhs, lhs, lhs);
+      fe_mul<C>(rhs, xx, yy);
+      fe_mul_k<C>(rhs, rhs, C::D2);
+      rejected = !(fe_is_canonical<C>(rx) && fe_is_canonical<C>(ry) && fe_eq<C>(lhs, rhs));
+    }
+  }
+  fe_set<C>(p.z, C::ONE);
+  fe_mul<C>(p.t, p.x, p.y);  // from_affine
+  ed_set_identity<C>(q);
+  const uint8_t* __restrict__ k = scalars + idx * 32;
+  // curve25519.rs:746-757: per bit, MSB first: double, add, keep the sum if the bit is set
+  for (int bit = 255; bit >= 0; --bit) {
+    uint32_t byte = k[31 - (bit >> 3)];
+    bool take = (byte >> (bit & 7)) & 1u;
+    ed_dbl<C>(q, q);
+    EdPt<C> added;
+    ed_add<C>(added, q, p);
+    fe_select<C>(q.x, take, added.x, q.x);
+    fe_select<C>(q.y, take, added.y, q.y);
+    fe_select<C>(q.z, take, added.z, q.z);
+    fe_select<C>(q.t, take, added.t, q.t);
+  }
+  if (active) ed_store_result<C>(idx, q, rejected, out, flags, proj, opts);
+  }  // grid-stride
+}
+
+// table[w][d] (d = 1..15): x, y, t = x*y Montgomery limbs, 3L words per entry
+template <class C>
+__global__ void __launch_bounds__(WG) k_ed_scalarmul_base(size_t n, const uint8_t* __restrict__ scalars,
+                                                          const uint32_t* __restrict__ table,
+                                                          uint8_t* __restrict__ out, uint8_t* __restrict__ flags,
+                                                          uint8_t* __restrict__ proj, uint32_t opts) {
+  constexpr int L = C::L;
+  for (size_t base = (size_t)blockIdx.x * WG; base < n; base += (size_t)gridDim.x * WG) {
+  const size_t gid = base + threadIdx.x;
+  const bool active = gid < n;
+  const size_t idx = active ? gid : n - 1;
+  const uint8_t* __restrict__ k = scalars + idx * 32;
+  EdPt<C> q;
+  ed_set_identity<C>(q);
+  for (int w = 0; w < 64; ++w) {
+    uint32_t byte = k[31 - (w >> 1)];  // indexes the big-endian scalar (curve25519.rs:842-846)
+    uint32_t d = (w & 1) ? (byte >> 4) : (byte & 0x0f);
+    EdPt<C> sel;
+    const uint32_t* __restrict__ e = table + ((size_t)w * 16 + d) * (3 * L);
+#pragma unroll
+    for (int i = 0; i < L; ++i) { sel.x.v[i] = e[i]; sel.y.v[i] = e[L + i]; sel.t.v[i] = e[2 * L + i]; }
+    fe_set<C>(sel.z, C::ONE);
+    if (d == 0) ed_set_identity<C>(sel);
+    ed_add<C>(q, q, sel);
+  }
+  if (active) ed_store_result<C>(idx, q, false, out, flags, proj, opts);
+  }  // grid-stride
+}
+
+}  // namespace eccx

@@ -1,0 +1,36 @@
+// Host-side launch interface between the C ABI (eccx_api.cpp) and the per-curve
+// kernel translation units (k_<curve>.hip, one per curve so they compile in parallel).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace eccx {
+
+struct CurveInfo {
+  int fb;           // field bytes
+  int sb;           // scalar bytes
+  int limbs;        // 32-bit limbs per field element
+  int table_words;  // words per comb-table entry (2L Weierstrass, 3L Edwards)
+  int row_words;    // words per variable-base scratch row (0: no scratch)
+  int edwards;
+};
+
+struct CurveOps {
+  CurveInfo info;
+  // variable base; internal opts are the OPT_* bits of kernels.hpp
+  hipError_t (*var)(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t* out,
+                    uint8_t* flags, uint8_t* proj, uint32_t* scratch, uint32_t opts);
+  hipError_t (*base)(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint32_t* table, uint8_t* out,
+                     uint8_t* flags, uint8_t* proj, uint32_t opts);
+};
+
+const CurveOps& ops_P256();
+const CurveOps& ops_P384();
+const CurveOps& ops_P521();
+const CurveOps& ops_BLS12_381();
+const CurveOps& ops_ED25519();
+
+constexpr int LAUNCH_WG = 256;
+
+}  // namespace eccx

@@ -1,0 +1,172 @@
+"""Thin Python host layer over the C ABI: a context per GPU, host-bytes and
+device-tensor entry points.  PyTorch is used only as plumbing (device memory, streams).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+from . import _lib
+
+# curve ids (include/eccx.h: eccx_curve)
+P256R1, P384R1, P521R1, BLS12_381_G1, ED25519 = 0, 1, 2, 3, 4
+CURVE_IDS = {"p256r1": P256R1, "p384r1": P384R1, "p521r1": P521R1, "bls12_381_g1": BLS12_381_G1, "ed25519": ED25519}
+CURVE_NAMES = {v: k for k, v in CURVE_IDS.items()}
+
+VALIDATE_POINTS = 1 << 0
+FLAG_FINITE, FLAG_INFINITY, FLAG_REJECTED = 0, 1, 2
+
+
+class EccxError(RuntimeError):
+    def __init__(self, code: int, detail: str = ""):
+        lib = _lib.load()
+        msg = lib.eccx_strerror(code).decode()
+        super().__init__(f"eccx error {code} ({msg}){': ' + detail if detail else ''}")
+        self.code = code
+
+
+def curve_id(curve) -> int:
+    if isinstance(curve, str):
+        return CURVE_IDS[curve]
+    return int(curve)
+
+
+def field_bytes(curve) -> int:
+    r = _lib.load().eccx_field_bytes(curve_id(curve))
+    if r < 0:
+        raise EccxError(r)
+    return r
+
+
+def scalar_bytes(curve) -> int:
+    r = _lib.load().eccx_scalar_bytes(curve_id(curve))
+    if r < 0:
+        raise EccxError(r)
+    return r
+
+
+def _proj_width(cid: int) -> int:
+    return (4 if cid == ED25519 else 3) * field_bytes(cid)
+
+
+class Engine:
+    """One engine context bound to one GPU (eccx_init / eccx_shutdown)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = _lib.load()
+        self._ctx = ctypes.c_void_p()
+        rc = self._lib.eccx_init(int(device), ctypes.byref(self._ctx))
+        if rc != 0:
+            raise EccxError(rc, f"eccx_init(device={device}) failed: no usable HIP device?")
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self._lib.eccx_shutdown(self._ctx)
+            self._ctx = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise EccxError(rc, self._lib.eccx_last_error(self._ctx).decode())
+
+    # ---- host buffers ------------------------------------------------------
+    def scalarmul_var(self, curve, scalars: bytes, points: bytes, *, validate: bool = False,
+                      want_proj: bool = False):
+        """out[i] = scalars[i] * points[i]; returns (affine bytes, flags[, proj bytes])."""
+        cid = curve_id(curve)
+        sb, fb = scalar_bytes(cid), field_bytes(cid)
+        if len(scalars) % sb:
+            raise ValueError("scalars length is not a multiple of the scalar size")
+        n = len(scalars) // sb
+        if len(points) != n * 2 * fb:
+            raise ValueError("points length does not match the number of scalars")
+        out = ctypes.create_string_buffer(max(1, n * 2 * fb))
+        flags = ctypes.create_string_buffer(max(1, n))
+        proj = ctypes.create_string_buffer(max(1, n * _proj_width(cid))) if want_proj else None
+        rc = self._lib.eccx_scalarmul_var(self._ctx, cid, n, scalars, points, out, flags, proj,
+                                          VALIDATE_POINTS if validate else 0)
+        self._check(rc)
+        res = (out.raw[: n * 2 * fb], flags.raw[:n])
+        return res + (proj.raw[: n * _proj_width(cid)],) if want_proj else res
+
+    def scalarmul_base(self, curve, scalars: bytes, *, want_proj: bool = False):
+        """out[i] = scalars[i] * G via the fixed-base comb table."""
+        cid = curve_id(curve)
+        sb, fb = scalar_bytes(cid), field_bytes(cid)
+        if len(scalars) % sb:
+            raise ValueError("scalars length is not a multiple of the scalar size")
+        n = len(scalars) // sb
+        out = ctypes.create_string_buffer(max(1, n * 2 * fb))
+        flags = ctypes.create_string_buffer(max(1, n))
+        proj = ctypes.create_string_buffer(max(1, n * _proj_width(cid))) if want_proj else None
+        rc = self._lib.eccx_scalarmul_base(self._ctx, cid, n, scalars, out, flags, proj, 0)
+        self._check(rc)
+        res = (out.raw[: n * 2 * fb], flags.raw[:n])
+        return res + (proj.raw[: n * _proj_width(cid)],) if want_proj else res
+
+    def comb_table(self, curve) -> bytes:
+        """The fixed-base table in the reference's on-disk layout (NW x 15 x (x||y))."""
+        cid = curve_id(curve)
+        size = 2 * scalar_bytes(cid) * 15 * 2 * field_bytes(cid)
+        out = ctypes.create_string_buffer(size)
+        self._check(self._lib.eccx_comb_table(self._ctx, cid, out))
+        return out.raw
+
+    # ---- device tensors (torch.uint8, resident on this engine's GPU) -----------
+    def scalarmul_var_t(self, curve, scalars, points, out=None, flags=None, proj=None, *,
+                        validate: bool = False, stream: Optional[int] = None):
+        """Device-resident variant: tensors are torch.uint8 CUDA tensors; the launch is
+        enqueued on `stream` (raw hipStream_t handle; default: torch's current stream)."""
+        import torch
+
+        cid = curve_id(curve)
+        sb, fb = scalar_bytes(cid), field_bytes(cid)
+        n = scalars.numel() // sb
+        if out is None:
+            out = torch.empty((n, 2 * fb), dtype=torch.uint8, device=scalars.device)
+        if flags is None:
+            flags = torch.empty((n,), dtype=torch.uint8, device=scalars.device)
+        for t in (scalars, points, out, flags) + ((proj,) if proj is not None else ()):
+            if not (t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()):
+                raise ValueError("tensors must be contiguous torch.uint8 CUDA tensors")
+        if stream is None:
+            stream = torch.cuda.current_stream(scalars.device).cuda_stream
+        rc = self._lib.eccx_scalarmul_var_dev(self._ctx, cid, n, scalars.data_ptr(), points.data_ptr(),
+                                              out.data_ptr(), flags.data_ptr(),
+                                              proj.data_ptr() if proj is not None else None,
+                                              VALIDATE_POINTS if validate else 0, stream)
+        self._check(rc)
+        return out, flags
+
+    def scalarmul_base_t(self, curve, scalars, out=None, flags=None, proj=None, *, stream: Optional[int] = None):
+        import torch
+
+        cid = curve_id(curve)
+        sb, fb = scalar_bytes(cid), field_bytes(cid)
+        n = scalars.numel() // sb
+        if out is None:
+            out = torch.empty((n, 2 * fb), dtype=torch.uint8, device=scalars.device)
+        if flags is None:
+            flags = torch.empty((n,), dtype=torch.uint8, device=scalars.device)
+        for t in (scalars, out, flags) + ((proj,) if proj is not None else ()):
+            if not (t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()):
+                raise ValueError("tensors must be contiguous torch.uint8 CUDA tensors")
+        if stream is None:
+            stream = torch.cuda.current_stream(scalars.device).cuda_stream
+        rc = self._lib.eccx_scalarmul_base_dev(self._ctx, cid, n, scalars.data_ptr(), out.data_ptr(),
+                                               flags.data_ptr(), proj.data_ptr() if proj is not None else None,
+                                               0, stream)
+        self._check(rc)
+        return out, flags

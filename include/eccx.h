@@ -1,0 +1,124 @@
+/* eccx.h -- C ABI of the MI355X batched scalar-multiplication engine.
+ *
+ * Drop-in boundary for eccoxide's scalar-multiplication hot path.  The reference
+ * (vincenthz/eccoxide, Rust) has no FFI or plugin layer: the seam is the trait +
+ * inherent methods listed below, one point and one scalar per call.  Each entry
+ * point here is the batched, C-callable form of one of them; INTEGRATION.md shows
+ * the Rust `extern "C"` binding a maintainer would add.
+ *
+ *   eccx_scalarmul_var[_dev]   impl Mul<&Scalar> for &Point      src/curve/fiat/curve_macros.rs:321-327
+ *                              -> Point::scale                   curve_macros.rs:47-49 (a=-3), :103-105 (a=0)
+ *                              -> projective::Point::scale_{am3,a0}_ct   src/curve/projective.rs:905-918
+ *                              edwards25519: Point::scale        src/curve/curve25519.rs:746-762
+ *   eccx_scalarmul_base[_dev]  Point::mul_base / CurveGroup::mul_base
+ *                              curve_macros.rs:55-63, :111-119; src/curve/group.rs:28-70
+ *                              -> mul_base_table_{am3,a0}        projective.rs:945-981
+ *                              edwards25519: Point::mul_base     curve25519.rs:840-851
+ *   output normalisation       Point::to_affine / to_affine_ct   curve_macros.rs:247-268,
+ *                              projective.rs:655-682, curve25519.rs:663-666
+ *   eccx_comb_table            COMB_TABLE constants              src/params/comb/<curve>.rs
+ *
+ * Byte conventions are the reference's:
+ *   - Weierstrass curves (p256r1, p384r1, p521r1, BLS12-381 G1): field elements and
+ *     scalars are big-endian, FB / SB bytes (field_macros.rs:6-29).
+ *   - edwards25519: field elements little-endian (curve25519.rs:138); the SCALAR is the
+ *     32-byte BIG-endian string the reference's loops index (Scalar::to_bytes_be,
+ *     curve25519.rs:761, :842).
+ *   - a point is its affine pair x||y, 2*FB bytes.  The Weierstrass point at infinity has
+ *     no affine form (to_affine -> None, projective.rs:666-668): it is reported through
+ *     the flag array with x = y = 0 bytes.
+ *   - scalars are used as given: the ladder multiplies by the integer the SB bytes
+ *     encode (projective.rs:871-896 accepts any byte string).  For P in the prime-order
+ *     subgroup that equals (k mod n)*P.
+ *
+ * All functions return 0 on success or a negative ECCX_ERR_* code; none aborts.
+ * A context is bound to one GPU; calls on one context are serialised by the caller or
+ * issued on different streams (the constant tables are read-only after first use; the
+ * variable-base scratch slab is per context, so concurrent variable-base calls need
+ * one context each).
+ */
+#ifndef ECCX_H
+#define ECCX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  ECCX_P256R1 = 0,       /* src/curve/sec2/p256r1.rs */
+  ECCX_P384R1 = 1,       /* src/curve/sec2/p384r1.rs */
+  ECCX_P521R1 = 2,       /* src/curve/sec2/p521r1.rs */
+  ECCX_BLS12_381_G1 = 3, /* src/curve/bls12_381/g1.rs */
+  ECCX_ED25519 = 4       /* src/curve/curve25519.rs (twisted Edwards form) */
+} eccx_curve;
+
+enum {
+  ECCX_OK = 0,
+  ECCX_ERR_CURVE = -1, /* unknown curve id */
+  ECCX_ERR_ARG = -2,   /* null pointer / bad size */
+  ECCX_ERR_HIP = -3,   /* a HIP call failed; see eccx_last_error() */
+  ECCX_ERR_NOMEM = -4
+};
+
+/* option bits */
+enum {
+  ECCX_VALIDATE_POINTS = 1u << 0 /* reject input points that are non-canonical or off the curve
+                                    (PointAffine::from_coordinate, src/curve/affine.rs:90-119):
+                                    flag 2, zero output */
+};
+
+/* flag values written per unit */
+enum { ECCX_FLAG_FINITE = 0, ECCX_FLAG_INFINITY = 1, ECCX_FLAG_REJECTED = 2 };
+
+typedef struct eccx_ctx eccx_ctx;
+
+/* sizes: field bytes FB, scalar bytes SB, comb windows NW = 2*SB; <0 on bad curve */
+int eccx_field_bytes(int curve);
+int eccx_scalar_bytes(int curve);
+
+/* Create / destroy a context on HIP device `device`. */
+int eccx_init(int device, eccx_ctx** out_ctx);
+void eccx_shutdown(eccx_ctx* ctx);
+const char* eccx_last_error(const eccx_ctx* ctx);
+const char* eccx_strerror(int code);
+
+/* Variable base: out[i] = scalars[i] * points[i].
+ *   scalars : n x SB          points : n x 2FB (affine x||y)
+ *   out     : n x 2FB         flags  : n bytes (ECCX_FLAG_*)
+ *   proj    : NULL, or n x 3FB (edwards25519: n x 4FB) receiving the reference's
+ *             un-normalised result coordinates X||Y||Z(||T), canonical bytes
+ * Host-pointer form: copies in, runs, copies out, synchronises. */
+int eccx_scalarmul_var(eccx_ctx* ctx, int curve, size_t n, const uint8_t* scalars, const uint8_t* points,
+                       uint8_t* out, uint8_t* flags, uint8_t* proj, uint32_t opts);
+
+/* Fixed base: out[i] = scalars[i] * G (comb table, built once per context and curve). */
+int eccx_scalarmul_base(eccx_ctx* ctx, int curve, size_t n, const uint8_t* scalars, uint8_t* out,
+                        uint8_t* flags, uint8_t* proj, uint32_t opts);
+
+/* Device-pointer forms: every buffer is device memory of ctx's GPU, the work is
+ * enqueued on `stream` (a hipStream_t; NULL = the context's own stream) and the call
+ * returns without synchronising. */
+int eccx_scalarmul_var_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_scalars, const void* d_points,
+                           void* d_out, void* d_flags, void* d_proj, uint32_t opts, void* stream);
+int eccx_scalarmul_base_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_scalars, void* d_out,
+                            void* d_flags, void* d_proj, uint32_t opts, void* stream);
+
+/* The fixed-base comb table in the reference's on-disk layout (src/params/comb/<curve>.rs):
+ * NW x 15 entries (j+1)*16^i*G as x||y, FB bytes each, big-endian (little-endian for
+ * edwards25519).  `out` is host memory of NW*15*2*FB bytes. */
+int eccx_comb_table(eccx_ctx* ctx, int curve, uint8_t* out);
+
+/* Split a host batch into contiguous shards over several contexts (one per GPU),
+ * run them concurrently and gather into the caller's host buffers. */
+int eccx_scalarmul_var_sharded(eccx_ctx** ctxs, int nctx, int curve, size_t n, const uint8_t* scalars,
+                               const uint8_t* points, uint8_t* out, uint8_t* flags, uint32_t opts);
+int eccx_scalarmul_base_sharded(eccx_ctx** ctxs, int nctx, int curve, size_t n, const uint8_t* scalars,
+                                uint8_t* out, uint8_t* flags, uint32_t opts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ECCX_H */
