@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path's headline benchmark (BASELINE.json).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--no-cpu-baseline]
+
+A "step" is one pass of the hot path over one batch of synthetic input that is already
+resident in HBM.  At N=1 the workload is BASELINE.json configs[1]: p256r1 variable-base
+scalar multiplication, batch = 2^20 (scalars uniform in [1, n), bases r_i*G).  For N>1 the
+driver launches one process per GPU (torch.distributed.run); every rank runs the same
+per-GPU batch (weak scaling), there is no data-path collective, and the step ends with the
+RCCL gather of the result bytes to rank 0.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      algorithmic HBM bytes (160 B per p256 unit) / kernel time
+                vs the 8 TB/s HBM peak -- the metric asks for it; the path is integer-VALU
+                bound, so the fraction is tiny by construction
+  valu          the roofline that actually binds: multiply-accumulates issued per second
+                against the v_mad_u64_u32 issue peak measured on this chip
+  cpu_baseline  the oracle (C restatement of the reference algorithm, kind "port") timed on
+                the host cores over a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (curve, op, per-GPU batch, algorithmic bytes per unit, field mul+sqr per unit, MACs per field mul)
+    "p256r1_var_2^20": ("p256r1", "var", 1 << 20, 160, 257 * 13 + 77 * 14, 8 * 8 + 8 * 5),
+    "ed25519_base_2^20": ("ed25519", "base", 1 << 20, 96, 64 * 9, 2 * 8 * 8),
+    "p384r1_var_2^19": ("p384r1", "var", 1 << 19, 240, 385 * 13 + 109 * 14, 12 * 12 + 12 * 10),
+    "p521r1_var_2^19": ("p521r1", "var", 1 << 19, 330, 529 * 13 + 145 * 14, 2 * 17 * 17),
+    "bls12_381_g1_var_2^20": ("bls12_381_g1", "var", 1 << 20, 224, 257 * 9 + 77 * 14, 2 * 12 * 12),
+}
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# v_mad_u64_u32 issue peak measured by tools/ubench/valu_rates.hip on MI355X
+# (profiles/r01_valu_rates.jsonl): 33.0e12 lane-MACs/s with 8 waves per SIMD.
+MAC_PEAK_PER_S = 33.0e12
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="p256r1_var_2^20", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=1 << 16)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import eccoxide_amd as E
+    from eccoxide_amd import workload as W
+    from eccoxide_amd.dist import gather_to_root
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    curve, op, n, alg_bytes, field_muls, macs_per_mul = WORKLOADS[args.workload]
+    fb, sb = E.field_bytes(curve), E.scalar_bytes(curve)
+    eng = E.Engine(dev.index)
+
+    # synthetic inputs, resident in HBM before the timed region (every rank its own shard seed)
+    ks = torch.from_numpy(W.random_scalars(curve, n, seed=10 + rank)).to(dev)
+    if op == "var":
+        rs = torch.from_numpy(W.random_scalars(curve, n, seed=1000 + rank)).to(dev)
+        pts, _ = eng.scalarmul_base_t(curve, rs)  # r_i * G: bases in the prime-order subgroup
+        del rs
+    else:
+        eng.scalarmul_base_t(curve, ks[:256].contiguous())  # builds the comb table
+        pts = None
+    out = torch.empty((n, 2 * fb), dtype=torch.uint8, device=dev)
+    flags = torch.empty((n,), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    sizes = [n] * world
+
+    def step():
+        if op == "var":
+            eng.scalarmul_var_t(curve, ks, pts, out, flags, stream=stream.cuda_stream)
+        else:
+            eng.scalarmul_base_t(curve, ks, out, flags, stream=stream.cuda_stream)
+
+    def gather():
+        if world > 1:
+            return gather_to_root(out, sizes), gather_to_root(flags, sizes)
+        return out, flags
+
+    for _ in range(args.warmup):
+        step()
+        gather()
+    torch.cuda.synchronize(dev)
+
+    # kernel-only time of the dominant kernel, HIP events on the launch stream
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record(stream)
+        step()
+        ev[i][1].record(stream)
+        gather()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+
+    if world > 1:
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(t[0]), float(t[1])
+
+    # correctness gate on the timed buffers: sampled comparison with the oracle (rank 0)
+    parity = None
+    cpu = None
+    if rank == 0:
+        from tests import oracle_lib
+
+        ora = oracle_lib.load()
+        idx = torch.randperm(n, generator=torch.Generator().manual_seed(1))[:256].sort().values.to(dev)
+        s_k = ks[idx].cpu().numpy().tobytes()
+        if op == "var":
+            w_out, w_inf, _ = ora.var(curve, s_k, pts[idx].cpu().numpy().tobytes(), threads=8)
+        else:
+            w_out, w_inf, _ = ora.base(curve, s_k, threads=8)
+        parity = (out[idx].cpu().numpy().tobytes() == w_out) and (flags[idx].cpu().numpy().tobytes() == w_inf)
+        if not args.no_cpu_baseline:
+            cores = min(16, os.cpu_count() or 1)
+            m = min(n, args.cpu_sample)
+            c_k = ks[:m].cpu().numpy().tobytes()
+            c_p = pts[:m].cpu().numpy().tobytes() if op == "var" else None
+            t1 = time.perf_counter()
+            if op == "var":
+                ora.var(curve, c_k, c_p, threads=cores)
+            else:
+                ora.base(curve, c_k, threads=cores)
+            dt = time.perf_counter() - t1
+            cpu = {"value": m / dt, "unit": "scalarmuls/s", "cores": cores, "kind": "port",
+                   "sample": f"first {m} units of the same {args.workload} batch, oracle/eccx_oracle.c "
+                             f"(C restatement of the reference algorithm), {cores} threads, {dt:.2f} s"}
+
+    if rank == 0:
+        total_units = n * world * args.steps
+        value = total_units / elapsed
+        ach = alg_bytes * n / (kernel_ms * 1e-3) / 1e9
+        mac_rate = field_muls * macs_per_mul * n / (kernel_ms * 1e-3)
+        line = {
+            "metric": "variable-base scalarmuls/sec (batch) per GPU + achieved HBM GB/s vs roofline"
+            if op == "var" else "fixed-base scalarmuls/sec (batch) per GPU + achieved HBM GB/s vs roofline",
+            "value": value,
+            "unit": "scalarmuls/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "curve": curve, "op": op, "batch_per_gpu": n,
+                       "global_batch": n * world, "parallelism": f"shard{world}" if world > 1 else "single",
+                       "gather": "rccl gather to rank 0 inside the step" if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": kernel_ms, "alg_bytes_per_unit": alg_bytes,
+                         "note": "integer-VALU bound path; see valu"},
+            "valu": {"bound": "v_mad_u64_u32 issue", "achieved": mac_rate / 1e12, "peak": MAC_PEAK_PER_S / 1e12,
+                     "unit": "T MAC32/s", "frac": mac_rate / MAC_PEAK_PER_S,
+                     "macs_per_unit": field_muls * macs_per_mul},
+            "cpu_baseline": cpu,
+            "parity_sample_ok": parity,
+        }
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

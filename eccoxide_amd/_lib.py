@@ -48,6 +48,14 @@ def load() -> ctypes.CDLL:
             f"{LIB_PATH} not found: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback."
         )
+    # PyTorch-ROCm wheels bundle their own libamdhip64.so.7.  Whichever HIP runtime is
+    # mapped first serves the whole process (same soname), and torch cannot find a GPU
+    # when the system runtime got there first: import torch before dlopen-ing the engine
+    # so both share torch's runtime.  (C/C++ hosts that never load torch use /opt/rocm's.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

@@ -272,7 +272,7 @@ int eccx_scalarmul_var_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_sca
   if (n == 0) return ECCX_OK;
   if (!d_scalars || !d_points || !d_out || !d_flags) return ECCX_ERR_ARG;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+  hipStream_t s = static_cast<hipStream_t>(stream);  // NULL = HIP's default stream
   return launch_var(ctx, ops, n, static_cast<const uint8_t*>(d_scalars), static_cast<const uint8_t*>(d_points),
                     static_cast<uint8_t*>(d_out), static_cast<uint8_t*>(d_flags), static_cast<uint8_t*>(d_proj),
                     kopts_of(opts), s);
@@ -289,7 +289,7 @@ int eccx_scalarmul_base_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_sc
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   int rc = ensure_comb(ctx, curve, ops);
   if (rc) return rc;
-  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+  hipStream_t s = static_cast<hipStream_t>(stream);  // NULL = HIP's default stream
   size_t need = (n + eccx::LAUNCH_WG - 1) / eccx::LAUNCH_WG;
   int grid = (int)std::max<size_t>(1, std::min(need, (size_t)ctx->cus * 8));
   HIP_TRY(ctx, ops->base(grid, s, n, static_cast<const uint8_t*>(d_scalars), ctx->comb[curve],

@@ -1,0 +1,75 @@
+"""Multi-GPU layer: one process per GPU (torch.distributed; backend "nccl" is RCCL over
+xGMI on ROCm, "gloo" on CPU for tests).
+
+Units (scalar, base) are independent, so the batch is split into contiguous shards
+ and every rank runs the single-GPU path on its shard with NO data-path
+collective.  The only exchange is the final gather of the result bytes to rank 0 — one
+message of (n/world) * 2FB bytes per peer, each over its own point-to-point xGMI link into
+the root.  The reference has no distributed code at all; this is the batch API the build
+adds around `&Point * &Scalar` (src/curve/fiat/curve_macros.rs:321-327).
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from .workload import shard_bounds
+
+
+def gather_to_root(local: torch.Tensor, sizes, root: int = 0, group=None) -> Optional[torch.Tensor]:
+    """Gather variable-length first-dimension shards to `root`; returns the concatenation on
+    root, None elsewhere.  Shards may be ragged (n not divisible by world)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if world == 1:
+        return local
+    rest = tuple(local.shape[1:])
+    if len(set(sizes)) == 1:
+        # equal shards: a single gather
+        bufs = [torch.empty((sizes[0],) + rest, dtype=local.dtype, device=local.device) for _ in range(world)] \
+            if rank == root else None
+        dist.gather(local.contiguous(), bufs, dst=root, group=group)
+        return torch.cat(bufs, dim=0) if rank == root else None
+    # ragged: point-to-point into the root
+    if rank == root:
+        parts = []
+        reqs = []
+        for r in range(world):
+            if r == root:
+                parts.append(local)
+            else:
+                buf = torch.empty((sizes[r],) + rest, dtype=local.dtype, device=local.device)
+                if sizes[r]:
+                    reqs.append(dist.irecv(buf, src=r, group=group))
+                parts.append(buf)
+        for q in reqs:
+            q.wait()
+        return torch.cat(parts, dim=0)
+    if sizes[rank]:
+        dist.send(local.contiguous(), dst=root, group=group)
+    return None
+
+
+def sharded_scalarmul(compute: Callable[[torch.Tensor, Optional[torch.Tensor]], Tuple[torch.Tensor, torch.Tensor]],
+                      scalars: torch.Tensor, points: Optional[torch.Tensor], *, gather: bool = True, root: int = 0,
+                      group=None):
+    """Run `compute(scalars_shard, points_shard) -> (out, flags)` on this rank's contiguous
+    shard of the global batch and gather the results on `root`.
+
+    `scalars` / `points` are the GLOBAL (n x SB / n x 2FB) uint8 tensors, identical on every
+    rank (or at least valid on the rank's own shard).  Returns (out, flags) for the whole
+    batch on root (None, None elsewhere) when gather=True, else this rank's shard results.
+    """
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n = scalars.shape[0]
+    lo, hi = shard_bounds(n, world, rank)
+    out, flags = compute(scalars[lo:hi], points[lo:hi] if points is not None else None)
+    if not gather or world == 1:
+        return out, flags
+    sizes = [shard_bounds(n, world, r)[1] - shard_bounds(n, world, r)[0] for r in range(world)]
+    g_out = gather_to_root(out, sizes, root, group)
+    g_flags = gather_to_root(flags, sizes, root, group)
+    return g_out, g_flags

@@ -99,8 +99,9 @@ int eccx_scalarmul_base(eccx_ctx* ctx, int curve, size_t n, const uint8_t* scala
                         uint8_t* flags, uint8_t* proj, uint32_t opts);
 
 /* Device-pointer forms: every buffer is device memory of ctx's GPU, the work is
- * enqueued on `stream` (a hipStream_t; NULL = the context's own stream) and the call
- * returns without synchronising. */
+ * enqueued on `stream` (a hipStream_t; NULL = HIP's default stream) and the call
+ * returns without synchronising.  (The first fixed-base call per curve builds the comb
+ * table on the context's own stream and waits for it.) */
 int eccx_scalarmul_var_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_scalars, const void* d_points,
                            void* d_out, void* d_flags, void* d_proj, uint32_t opts, void* stream);
 int eccx_scalarmul_base_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_scalars, void* d_out,

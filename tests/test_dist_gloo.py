@@ -1,0 +1,70 @@
+"""The N>1 path (contiguous shards, no data-path collective, one gather to rank 0) with
+world_size 2 on the gloo backend.  The per-rank compute is the CPU oracle here (test
+infrastructure standing in for the GPU engine); what is under test is the sharding and
+gather logic of eccoxide_amd/dist.py.  CPU only."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from eccoxide_amd import workload as W
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, curve, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from eccoxide_amd.dist import sharded_scalarmul
+        from tests import oracle_lib
+
+        ora = oracle_lib.load()
+        ks = torch.from_numpy(W.random_scalars(curve, n, seed=11))
+        rs = W.random_scalars(curve, n, seed=12)
+        pts_b, _, _ = ora.base(curve, rs.tobytes(), threads=2)
+        pts = torch.frombuffer(bytearray(pts_b), dtype=torch.uint8).reshape(n, -1)
+
+        def compute(k, p):
+            o, f, _ = ora.var(curve, k.contiguous().numpy().tobytes(), p.contiguous().numpy().tobytes(), threads=2)
+            fb2 = p.shape[1]
+            return (torch.frombuffer(bytearray(o), dtype=torch.uint8).reshape(-1, fb2) if len(o) else torch.empty((0, fb2), dtype=torch.uint8),
+                    torch.frombuffer(bytearray(f), dtype=torch.uint8) if len(f) else torch.empty((0,), dtype=torch.uint8))
+
+        out, flags = sharded_scalarmul(compute, ks, pts)
+        if rank == 0:
+            full_o, full_f, _ = ora.var(curve, ks.numpy().tobytes(), pts.numpy().tobytes(), threads=2)
+            q.put((out.numpy().tobytes() == full_o, flags.numpy().tobytes() == full_f, tuple(out.shape)))
+        else:
+            assert out is None and flags is None
+            q.put(("nonroot", True, None))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [64, 37])  # equal shards, and ragged shards (19 / 18)
+def test_world2_sharded_matches_single(n):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, "p256r1", q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    root = [r for r in res if r[0] != "nonroot"][0]
+    assert root[0] is True and root[1] is True and root[2] == (n, 64)

@@ -1,0 +1,291 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (include/eccx.h), against
+the CPU oracle on the same seeded inputs, against the committed golden fixtures, and — at
+BASELINE.json's full batch sizes — through size-independent properties.  Bar: bit-exact
+(bytes and flags; un-normalised X:Y:Z too where checked).
+"""
+import hashlib
+import random
+
+import numpy as np
+import pytest
+
+from eccoxide_amd import workload as W
+from tests.oracle_lib import golden
+
+pytestmark = pytest.mark.gpu
+
+WEI = ["p256r1", "p384r1", "p521r1", "bls12_381_g1"]
+ALL = WEI + ["ed25519"]
+
+
+_SIZES = {"p256r1": (32, 32), "p384r1": (48, 48), "p521r1": (66, 66), "bls12_381_g1": (48, 32), "ed25519": (32, 32)}
+
+
+def sizes(curve):
+    """(field bytes, scalar bytes)"""
+    return _SIZES[curve]
+
+
+def gen_point_bytes(oracle, curve):
+    one = (1).to_bytes(sizes(curve)[1], "big")
+    return oracle.base(curve, one)[0]
+
+
+def bases(oracle, curve, n, seed):
+    """r_i * G, guaranteed in the prime-order subgroup."""
+    rs = W.random_scalars(curve, n, seed=seed).tobytes()
+    return oracle.base(curve, rs, threads=16)[0]
+
+
+# ---- seeded random batches vs the oracle, incl. ragged batch sizes -----------------------
+@pytest.mark.parametrize("curve", ALL)
+@pytest.mark.parametrize("n", [1, 63, 257, 1500])
+def test_var_matches_oracle(engine, oracle, curve, n):
+    ks = W.random_scalars(curve, n, seed=100 + n).tobytes()
+    pts = bases(oracle, curve, n, seed=200 + n)
+    want_out, want_inf, want_proj = oracle.var(curve, ks, pts, threads=16)
+    out, flags, proj = engine.scalarmul_var(curve, ks, pts, want_proj=True)
+    assert out == want_out
+    assert flags == want_inf
+    assert proj == want_proj  # same un-normalised (X:Y:Z[:T]) residues as the reference algorithm
+
+
+@pytest.mark.parametrize("curve", ALL)
+@pytest.mark.parametrize("n", [1, 65, 1500])
+def test_base_matches_oracle(engine, oracle, curve, n):
+    ks = W.random_scalars(curve, n, seed=300 + n).tobytes()
+    want_out, want_inf, want_proj = oracle.base(curve, ks, threads=16)
+    out, flags, proj = engine.scalarmul_base(curve, ks, want_proj=True)
+    assert out == want_out and flags == want_inf and proj == want_proj
+
+
+def test_empty_batch(engine):
+    for curve in ALL:
+        out, flags = engine.scalarmul_var(curve, b"", b"")
+        assert out == b"" and flags == b""
+        out, flags = engine.scalarmul_base(curve, b"")
+        assert out == b"" and flags == b""
+
+
+# ---- edge scalars: 0, 1, n-1, n, n+1, all-ones ------------------------------------------
+@pytest.mark.parametrize("curve", ALL)
+def test_edge_scalars(engine, oracle, curve):
+    fb, sb = sizes(curve)
+    order = W.order(curve)
+    top = (1 << 521) - 1 if curve == "p521r1" else (1 << (8 * sb)) - 1
+    vals = [0, 1, 2, 15, 16, 17, order - 1, order, order + 1, top, 1 << (8 * sb - 8)]
+    vals = [v for v in vals if v < (1 << (8 * sb))]
+    ks = b"".join(v.to_bytes(sb, "big") for v in vals)
+    n = len(vals)
+    g = gen_point_bytes(oracle, curve)
+    pts = g + bases(oracle, curve, n - 1, seed=5)
+    want = oracle.var(curve, ks, pts)
+    got = engine.scalarmul_var(curve, ks, pts, want_proj=True)
+    assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2]
+    # k = 0 and k = n give the neutral element
+    assert got[1][0] == 1 and got[1][vals.index(order)] == 1
+    if curve != "ed25519":
+        assert got[0][: 2 * fb] == bytes(2 * fb)
+    want = oracle.base(curve, ks)
+    got = engine.scalarmul_base(curve, ks, want_proj=True)
+    assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2]
+    # 1 * G == G
+    assert got[0][2 * fb: 4 * fb] == g
+
+
+# ---- the reference's own known-answer vectors, on the GPU ---------------------------------
+@pytest.mark.parametrize("curve", ["p256r1", "p384r1", "p521r1"])
+def test_nist_kg_on_gpu(engine, oracle, curve):
+    """src/tests/kats.rs:3-40: &Point::GENERATOR * &k for the NIST vectors."""
+    fb, sb = sizes(curve)
+    kats = golden("nist_kg.json")[curve]
+    ks = b"".join(bytes.fromhex(kv["k"]).rjust(sb, b"\0") for kv in kats)
+    want = b"".join(bytes.fromhex(kv["x"]).rjust(fb, b"\0") + bytes.fromhex(kv["y"]).rjust(fb, b"\0") for kv in kats)
+    out, flags = engine.scalarmul_var(curve, ks, gen_point_bytes(oracle, curve) * len(kats))
+    assert out == want and flags == bytes(len(kats))
+    out, flags = engine.scalarmul_base(curve, ks)
+    assert out == want and flags == bytes(len(kats))
+
+
+@pytest.mark.parametrize("curve", ["p256r1", "p384r1", "p521r1"])
+def test_rfc6979_on_gpu(engine, curve):
+    """src/protocol/ecdsa.rs:700-707 (public key = mul_base(secret)), :174 (r = x(kG) mod n)."""
+    fb, sb = sizes(curve)
+    v = golden("rfc6979.json")[curve]
+    ks = bytes.fromhex(v["secret"].rjust(2 * sb, "0")) + b"".join(bytes.fromhex(k["k"].rjust(2 * sb, "0")) for k in v["sign_kats"])
+    out, flags = engine.scalarmul_base(curve, ks)
+    assert out[: 2 * fb] == bytes.fromhex(v["ux"].rjust(2 * fb, "0")) + bytes.fromhex(v["uy"].rjust(2 * fb, "0"))
+    for i, kat in enumerate(v["sign_kats"], start=1):
+        x = int.from_bytes(out[i * 2 * fb: i * 2 * fb + fb], "big")
+        assert x % W.order(curve) == int(kat["r"], 16)
+
+
+def test_rfc8032_on_gpu(engine):
+    """src/protocol/ed25519.rs:271-315: seed -> clamp/reduce -> mul_base -> encoded public key."""
+    order = W.order("ed25519")
+    for v in golden("rfc8032.json"):
+        h = bytearray(hashlib.sha512(bytes.fromhex(v["seed"])).digest()[:32])
+        h[0] &= 248
+        h[31] &= 127
+        h[31] |= 64
+        a = int.from_bytes(bytes(h), "little") % order
+        out, flags = engine.scalarmul_base("ed25519", a.to_bytes(32, "big"))
+        x, y = int.from_bytes(out[:32], "little"), int.from_bytes(out[32:], "little")
+        assert (y | ((x & 1) << 255)).to_bytes(32, "little").hex() == v["public"]
+        assert flags == b"\0"
+
+
+def test_bls_g1_kats_on_gpu(engine, oracle):
+    """src/curve/bls12_381/g1.rs:605-692."""
+    v = golden("bls_g1.json")
+    g = gen_point_bytes(oracle, "bls12_381_g1")
+    for e in v["uncompressed"]:
+        k = e["k"].to_bytes(32, "big")
+        assert engine.scalarmul_var("bls12_381_g1", k, g)[0].hex() == e["bytes"]
+        assert engine.scalarmul_base("bls12_381_g1", k)[0].hex() == e["bytes"]
+    p = int(golden("params.json")["bls12_381_g1"]["p"], 16)
+    for e in v["compressed"]:
+        out, _ = engine.scalarmul_base("bls12_381_g1", e["k"].to_bytes(32, "big"))
+        enc = bytearray(bytes.fromhex(e["bytes"]))
+        sort_flag = bool(enc[0] & 0x20)
+        enc[0] &= 0x1F
+        assert bytes(enc) == out[:48]
+        assert sort_flag == (int.from_bytes(out[48:], "big") > (p - 1) // 2)
+
+
+@pytest.mark.parametrize("curve", ALL)
+def test_comb_table_matches_reference(engine, curve):
+    """The engine-built fixed-base table equals the reference's embedded COMB_TABLE
+    (src/params/comb/<curve>.rs): SHA-256 over the whole table + sampled windows."""
+    cs = golden("comb_samples.json")[curve]
+    raw = engine.comb_table(curve)
+    fb = cs["field_bytes"]
+    assert len(raw) == cs["windows"] * 15 * 2 * fb
+    assert hashlib.sha256(raw).hexdigest() == cs["sha256_xy_concat"]
+    for w, entries in cs["samples"].items():
+        for j, (xs, ys) in enumerate(entries):
+            off = (int(w) * 15 + j) * 2 * fb
+            assert raw[off: off + fb].hex() == xs and raw[off + fb: off + 2 * fb].hex() == ys
+
+
+# ---- input validation (PointAffine::from_coordinate, src/curve/affine.rs:90-119) ------------
+@pytest.mark.parametrize("curve", ALL)
+def test_point_validation(engine, oracle, curve):
+    fb, sb = sizes(curve)
+    n = 8
+    ks = W.random_scalars(curve, n, seed=77).tobytes()
+    pts = bytearray(bases(oracle, curve, n, seed=78))
+    good = bytes(pts)
+    pts[2 * fb * 1 + fb - 1 if curve != "ed25519" else 2 * fb * 1] ^= 1     # unit 1: x off the curve
+    pts[2 * fb * 3: 2 * fb * 3 + fb] = b"\xff" * fb                          # unit 3: x >= p (non-canonical)
+    if curve == "p521r1":
+        pts[2 * fb * 3] = 0x03
+    out, flags = engine.scalarmul_var(curve, ks, bytes(pts), validate=True)
+    want_out, want_inf, _ = oracle.var(curve, ks, good)
+    for i in range(n):
+        if i in (1, 3):
+            assert flags[i] == 2 and out[i * 2 * fb:(i + 1) * 2 * fb] == bytes(2 * fb)
+        else:
+            assert flags[i] == want_inf[i] and out[i * 2 * fb:(i + 1) * 2 * fb] == want_out[i * 2 * fb:(i + 1) * 2 * fb]
+
+
+# ---- reference properties at test sizes (src/tests/completeness.rs:60-117) -------------------
+@pytest.mark.parametrize("curve", ALL)
+def test_mul_base_matches_generic(engine, oracle, curve):
+    n = 512
+    ks = W.random_scalars(curve, n, seed=9).tobytes()
+    g = gen_point_bytes(oracle, curve)
+    a = engine.scalarmul_base(curve, ks)
+    b = engine.scalarmul_var(curve, ks, g * n)
+    assert a == b
+
+
+# ---- BASELINE.json full sizes: size-independent properties --------------------------------------
+def _full_size_check(engine, oracle, curve, n, seed):
+    """k_i * (r_i * G) == (k_i * r_i mod order) * G for every unit: crosses the variable-base
+    ladder, the comb path and (host big-int) scalar-field arithmetic; plus a sampled
+    comparison against the oracle."""
+    import torch
+
+    fb, sb = sizes(curve)
+    order = W.order(curve)
+    ks = W.random_scalars(curve, n, seed=seed)
+    rs = W.random_scalars(curve, n, seed=seed + 1)
+    d_k, d_r = torch.from_numpy(ks).cuda(), torch.from_numpy(rs).cuda()
+    pts, f0 = engine.scalarmul_base_t(curve, d_r)
+    out, flags = engine.scalarmul_var_t(curve, d_k, pts)
+    prod = np.empty((n, sb), dtype=np.uint8)
+    kb, rb = ks.tobytes(), rs.tobytes()
+    buf = bytearray(n * sb)
+    for i in range(n):
+        v = int.from_bytes(kb[i * sb:(i + 1) * sb], "big") * int.from_bytes(rb[i * sb:(i + 1) * sb], "big") % order
+        buf[i * sb:(i + 1) * sb] = v.to_bytes(sb, "big")
+    d_p = torch.frombuffer(buf, dtype=torch.uint8).reshape(n, sb).cuda()
+    out2, flags2 = engine.scalarmul_base_t(curve, d_p)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+    assert torch.equal(flags, flags2)
+    assert int(f0.max()) == 0
+    # checksum of everything + sampled oracle comparison
+    sample = np.random.Generator(np.random.PCG64(seed)).choice(n, size=512, replace=False)
+    sample.sort()
+    s_k = ks[sample].tobytes()
+    s_p = pts[torch.from_numpy(sample).cuda()].cpu().numpy().tobytes()
+    want_out, want_inf, _ = oracle.var(curve, s_k, s_p, threads=16)
+    got = out[torch.from_numpy(sample).cuda()].cpu().numpy().tobytes()
+    assert got == want_out
+    assert flags[torch.from_numpy(sample).cuda()].cpu().numpy().tobytes() == want_inf
+
+
+def test_full_size_p256r1(engine, oracle):
+    """BASELINE.json configs[1]: p256r1 variable-base, batch = 2^20."""
+    _full_size_check(engine, oracle, "p256r1", 1 << 20, seed=1000)
+
+
+def test_full_size_ed25519_mul_base(engine, oracle):
+    """BASELINE.json configs[2]: Ed25519 mul_base, batch = 2^20.  Properties: linearity
+    (a+b)*B == a*B + b*B checked through the variable-base kernel on a slice, and a
+    sampled oracle comparison."""
+    import torch
+
+    n = 1 << 20
+    order = W.order("ed25519")
+    ks = W.random_scalars("ed25519", n, seed=2000)
+    d_k = torch.from_numpy(ks).cuda()
+    out, flags = engine.scalarmul_base_t("ed25519", d_k)
+    torch.cuda.synchronize()
+    assert int(flags.max()) == 0
+    sample = np.random.Generator(np.random.PCG64(5)).choice(n, size=1024, replace=False)
+    sample.sort()
+    want_out, want_inf, _ = oracle.base("ed25519", ks[sample].tobytes(), threads=16)
+    assert out[torch.from_numpy(sample).cuda()].cpu().numpy().tobytes() == want_out
+    # k*B via comb == k*B via double-and-add for a 2^16 slice (curve25519.rs:1373-1387)
+    m = 1 << 16
+    g = oracle.base("ed25519", (1).to_bytes(32, "big"))[0]
+    d_g = torch.frombuffer(bytearray(g * m), dtype=torch.uint8).reshape(m, 64).cuda()
+    out2, flags2 = engine.scalarmul_var_t("ed25519", d_k[:m].contiguous(), d_g)
+    torch.cuda.synchronize()
+    assert torch.equal(out[:m], out2)
+
+
+@pytest.mark.parametrize("curve,n", [("p384r1", 1 << 17), ("p521r1", 1 << 16), ("bls12_381_g1", 1 << 18)])
+def test_large_batches_other_curves(engine, oracle, curve, n):
+    """BASELINE.json configs[3]/[4] curves at per-GPU sizes that keep the test short."""
+    _full_size_check(engine, oracle, curve, n, seed=3000 + n)
+
+
+def test_sharded_entry_point_single_gpu(engine, oracle):
+    """eccx_scalarmul_var_sharded with one context == the plain call."""
+    import ctypes
+
+    lib = engine._lib
+    n = 300
+    ks = W.random_scalars("p256r1", n, seed=4).tobytes()
+    pts = bases(oracle, "p256r1", n, seed=6)
+    out = ctypes.create_string_buffer(n * 64)
+    fl = ctypes.create_string_buffer(n)
+    arr = (ctypes.c_void_p * 1)(engine._ctx.value)
+    rc = lib.eccx_scalarmul_var_sharded(arr, 1, 0, n, ks, pts, out, fl, 0)
+    assert rc == 0
+    want = oracle.var("p256r1", ks, pts)
+    assert out.raw == want[0] and fl.raw == want[1]
