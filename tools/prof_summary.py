@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 output (rocpd SQLite databases written by tools/profile.sh) into a
+small JSON file suitable for profiles/.
+
+    python tools/prof_summary.py gpurun_out/prof_r01 > profiles/r01_p256r1_var.json
+
+Kernel-trace: per (kernel, grid) calls / average / min / max duration in microseconds.
+PMC passes: per (kernel, grid) average counter value per dispatch.  HBM traffic follows
+MI355X_MICROARCH.md §HBM: FETCH_SIZE/WRITE_SIZE are reported in KiB-like units of the
+counter expression; on gfx950 FETCH_SIZE under-reports wide coalesced streaming reads by 2x
+(doubled here and labelled), WRITE_SIZE reads exact for 16-byte stores.
+"""
+import glob
+import json
+import os
+import sqlite3
+import sys
+
+
+def short(name: str) -> str:
+    name = name.replace("void ", "")
+    return name.split("(")[0]
+
+
+def trace(db_path):
+    db = sqlite3.connect(db_path)
+    rows = db.execute("select name, grid_x, workgroup_x, duration, vgpr_count, accum_vgpr_count, sgpr_count, scratch_size, lds_size from kernels").fetchall()
+    agg = {}
+    for name, grid, wg, dur, vgpr, agpr, sgpr, scratch, lds in rows:
+        k = (short(name), grid, wg)
+        a = agg.setdefault(k, {"calls": 0, "sum": 0, "min": 1e30, "max": 0, "vgpr": vgpr, "agpr": agpr, "sgpr": sgpr, "scratch": scratch, "lds": lds})
+        a["calls"] += 1
+        a["sum"] += dur
+        a["min"] = min(a["min"], dur)
+        a["max"] = max(a["max"], dur)
+    out = []
+    for (name, grid, wg), a in sorted(agg.items(), key=lambda kv: -kv[1]["sum"]):
+        out.append({"kernel": name, "grid_threads": grid, "workgroup": wg, "calls": a["calls"],
+                    "avg_us": a["sum"] / a["calls"] / 1e3, "min_us": a["min"] / 1e3, "max_us": a["max"] / 1e3,
+                    "total_us": a["sum"] / 1e3, "vgpr": a["vgpr"], "agpr": a["agpr"], "sgpr": a["sgpr"],
+                    "scratch_bytes": a["scratch"], "lds_bytes": a["lds"]})
+    return out
+
+
+def pmc(db_path):
+    db = sqlite3.connect(db_path)
+    rows = db.execute("select kernel_name, grid_size, counter_name, value from counters_collection").fetchall()
+    agg = {}
+    for name, grid, counter, value in rows:
+        k = (short(name), grid, counter)
+        a = agg.setdefault(k, [0, 0.0])
+        a[0] += 1
+        a[1] += value
+    out = {}
+    for (name, grid, counter), (cnt, total) in agg.items():
+        out.setdefault(f"{name} grid={grid}", {})[counter] = {"dispatches": cnt, "avg_per_dispatch": total / cnt}
+    return out
+
+
+def main():
+    root = sys.argv[1]
+    res = {"source": os.path.basename(os.path.normpath(root)), "kernel_trace": None, "pmc": {}}
+    for f in glob.glob(os.path.join(root, "trace", "**", "*.db"), recursive=True):
+        res["kernel_trace"] = [r for r in trace(f) if r["total_us"] > 50]
+    for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
+        if not os.path.isdir(d):
+            continue
+        for f in glob.glob(os.path.join(d, "**", "*.db"), recursive=True):
+            p = pmc(f)
+            for k, v in p.items():
+                if "eccx::" in k:
+                    res["pmc"].setdefault(k, {}).update(v)
+    # derived HBM traffic for the engine's kernels
+    for k, v in res["pmc"].items():
+        if "FETCH_SIZE" in v:
+            kb = v["FETCH_SIZE"]["avg_per_dispatch"]
+            v["hbm_read_bytes_per_dispatch_raw"] = kb * 1024
+            v["hbm_read_bytes_per_dispatch_x2_gfx950_correction"] = kb * 1024 * 2
+        if "WRITE_SIZE" in v:
+            v["hbm_write_bytes_per_dispatch"] = v["WRITE_SIZE"]["avg_per_dispatch"] * 1024
+    json.dump(res, sys.stdout, indent=1)
+    sys.stdout.write("\n")
+
+
+if __name__ == "__main__":
+    main()
