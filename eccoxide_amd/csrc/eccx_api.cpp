@@ -48,6 +48,8 @@ struct eccx_ctx {
   std::mutex comb_mu;
   uint32_t* scratch = nullptr;
   size_t scratch_words = 0;
+  uint32_t* jac = nullptr;  // un-normalised results of the fast kernels
+  size_t jac_words = 0;
   std::mutex scratch_mu;
   std::string err;
 };
@@ -72,28 +74,50 @@ int grid_for(const eccx_ctx* ctx, size_t n) {
   return (int)std::max<size_t>(1, std::min(need, cap));
 }
 
-int ensure_scratch(eccx_ctx* ctx, const CurveOps* ops, int grid) {
-  size_t words = (size_t)grid * 16 * eccx::LAUNCH_WG * (size_t)ops->info.row_words;
-  std::lock_guard<std::mutex> g(ctx->scratch_mu);
-  if (words <= ctx->scratch_words) return ECCX_OK;
-  if (ctx->scratch) {
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+// grow-only device buffer owned by the context
+int ensure_buffer(eccx_ctx* ctx, uint32_t** buf, size_t* have, size_t words) {
+  if (words <= *have) return ECCX_OK;
+  if (*buf) {
     HIP_TRY(ctx, hipDeviceSynchronize());
-    HIP_TRY(ctx, hipFree(ctx->scratch));
-    ctx->scratch = nullptr;
-    ctx->scratch_words = 0;
+    HIP_TRY(ctx, hipFree(*buf));
+    *buf = nullptr;
+    *have = 0;
   }
-  HIP_TRY(ctx, hipMalloc(&ctx->scratch, words * sizeof(uint32_t)));
-  ctx->scratch_words = words;
+  HIP_TRY(ctx, hipMalloc(buf, words * sizeof(uint32_t)));
+  *have = words;
   return ECCX_OK;
 }
 
+int ensure_scratch(eccx_ctx* ctx, int row_words, int grid) {
+  size_t words = (size_t)grid * 16 * eccx::LAUNCH_WG * (size_t)row_words;
+  std::lock_guard<std::mutex> g(ctx->scratch_mu);
+  return ensure_buffer(ctx, &ctx->scratch, &ctx->scratch_words, words);
+}
+
+// Variable base.  mirror = run the reference-mirroring kernel (homogeneous RCB formulas,
+// un-normalised X:Y:Z available); otherwise the fast Jacobian kernel + batched
+// normalisation where the curve has one.
 int launch_var(eccx_ctx* ctx, const CurveOps* ops, size_t n, const uint8_t* d_scalars, const uint8_t* d_points,
-               uint8_t* d_out, uint8_t* d_flags, uint8_t* d_proj, uint32_t kopts, hipStream_t s) {
+               uint8_t* d_out, uint8_t* d_flags, uint8_t* d_proj, uint32_t kopts, bool mirror, hipStream_t s) {
   if (n == 0) return ECCX_OK;
   int grid = grid_for(ctx, n);
+  const bool fast = !mirror && ops->var_fast && !d_proj && !(kopts & K_OUT_TABLE);
+  if (fast) {
+    int rc = ensure_scratch(ctx, ops->info.row5_words, grid);
+    if (rc) return rc;
+    {
+      std::lock_guard<std::mutex> g(ctx->scratch_mu);
+      rc = ensure_buffer(ctx, &ctx->jac, &ctx->jac_words, n * (size_t)ops->info.jac_words);
+      if (rc) return rc;
+    }
+    HIP_TRY(ctx, ops->var_fast(grid, s, n, d_scalars, d_points, ctx->jac, d_flags, ctx->scratch, kopts));
+    size_t tiles = (n + (size_t)eccx::LAUNCH_WG * eccx::TO_AFFINE_U - 1) / ((size_t)eccx::LAUNCH_WG * eccx::TO_AFFINE_U);
+    int g2 = (int)std::max<size_t>(1, std::min(tiles, (size_t)ctx->cus * 4));
+    HIP_TRY(ctx, ops->to_affine_jac(g2, s, n, ctx->jac, d_out, d_flags));
+    return ECCX_OK;
+  }
   if (ops->info.row_words) {
-    int rc = ensure_scratch(ctx, ops, grid);
+    int rc = ensure_scratch(ctx, ops->info.row_words, grid);
     if (rc) return rc;
   }
   HIP_TRY(ctx, ops->var(grid, s, n, d_scalars, d_points, d_out, d_flags, d_proj, ctx->scratch, kopts));
@@ -125,7 +149,7 @@ int ensure_comb(eccx_ctx* ctx, int curve, const CurveOps* ops) {
   HIP_TRY(ctx, hipMemcpyAsync(d_k, k.data(), k.size(), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(d_tab, 0, rows * ops->info.table_words * sizeof(uint32_t), ctx->stream));
   int rc = launch_var(ctx, ops, rows, d_k, nullptr, reinterpret_cast<uint8_t*>(d_tab), nullptr, nullptr,
-                      K_BASE_IS_GENERATOR | K_OUT_TABLE, ctx->stream);
+                      K_BASE_IS_GENERATOR | K_OUT_TABLE, true, ctx->stream);
   if (rc) return rc;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   HIP_TRY(ctx, hipFree(d_k));
@@ -247,6 +271,7 @@ void eccx_shutdown(eccx_ctx* ctx) {
   for (auto& t : ctx->comb)
     if (t) (void)hipFree(t);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->jac) (void)hipFree(ctx->jac);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -275,7 +300,7 @@ int eccx_scalarmul_var_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_sca
   hipStream_t s = static_cast<hipStream_t>(stream);  // NULL = HIP's default stream
   return launch_var(ctx, ops, n, static_cast<const uint8_t*>(d_scalars), static_cast<const uint8_t*>(d_points),
                     static_cast<uint8_t*>(d_out), static_cast<uint8_t*>(d_flags), static_cast<uint8_t*>(d_proj),
-                    kopts_of(opts), s);
+                    kopts_of(opts), (opts & ECCX_MIRROR_REFERENCE) != 0, s);
 }
 
 int eccx_scalarmul_base_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_scalars, void* d_out, void* d_flags,
@@ -322,7 +347,7 @@ int eccx_comb_table(eccx_ctx* ctx, int curve, uint8_t* out) {
   HIP_TRY(ctx, hipMalloc(&d_o, aff.size()));
   HIP_TRY(ctx, hipMalloc(&d_f, rows));
   HIP_TRY(ctx, hipMemcpyAsync(d_k, k.data(), k.size(), hipMemcpyHostToDevice, ctx->stream));
-  int rc = launch_var(ctx, ops, rows, d_k, nullptr, d_o, d_f, nullptr, K_BASE_IS_GENERATOR, ctx->stream);
+  int rc = launch_var(ctx, ops, rows, d_k, nullptr, d_o, d_f, nullptr, K_BASE_IS_GENERATOR, false, ctx->stream);
   if (rc) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(aff.data(), d_o, aff.size(), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

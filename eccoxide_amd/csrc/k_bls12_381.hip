@@ -1,5 +1,5 @@
 // Kernel instantiations for BLS12_381 (see kernels.hpp).
-#include "kernels.hpp"
+#include "kernels_fast.hpp"
 #include "launch.hpp"
 
 namespace eccx {
@@ -14,9 +14,18 @@ hipError_t base_(int grid, hipStream_t s, size_t n, const uint8_t* scalars, cons
   hipLaunchKernelGGL(k_scalarmul_base<BLS12_381>, dim3(grid), dim3(WG), 0, s, n, scalars, table, out, flags, proj, opts);
   return hipGetLastError();
 }
+hipError_t var_fast_(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint8_t* points, uint32_t* jac,
+                     uint8_t* flags, uint32_t* scratch, uint32_t opts) {
+  hipLaunchKernelGGL(k_scalarmul_var_fast<BLS12_381>, dim3(grid), dim3(WG), 0, s, n, scalars, points, jac, flags, scratch, opts);
+  return hipGetLastError();
+}
+hipError_t to_affine_jac_(int grid, hipStream_t s, size_t n, const uint32_t* jac, uint8_t* out, uint8_t* flags) {
+  hipLaunchKernelGGL((k_batch_to_affine<BLS12_381, true, TO_AFFINE_U>), dim3(grid), dim3(WG), 0, s, n, jac, out, flags);
+  return hipGetLastError();
+}
 }  // namespace
 const CurveOps& ops_BLS12_381() {
-  static const CurveOps o = {{BLS12_381::FB, BLS12_381::SB, BLS12_381::L, 2 * BLS12_381::L, row_words<BLS12_381::L>(), 0}, var_, base_};
+  static const CurveOps o = {{BLS12_381::FB, BLS12_381::SB, BLS12_381::L, 2 * BLS12_381::L, row_words<BLS12_381::L>(), 0, row5_words<BLS12_381::L>(), row_words<BLS12_381::L>()}, var_, base_, var_fast_, to_affine_jac_};
   return o;
 }
 }  // namespace eccx

@@ -16,7 +16,7 @@ hipError_t base_(int grid, hipStream_t s, size_t n, const uint8_t* scalars, cons
 }
 }  // namespace
 const CurveOps& ops_ED25519() {
-  static const CurveOps o = {{ED25519::FB, ED25519::SB, ED25519::L, 3 * ED25519::L, 0, 1}, var_, base_};
+  static const CurveOps o = {{ED25519::FB, ED25519::SB, ED25519::L, 3 * ED25519::L, 0, 1, 0, 0}, var_, base_, nullptr, nullptr};
   return o;
 }
 }  // namespace eccx

@@ -1,5 +1,5 @@
 // Kernel instantiations for P256 (see kernels.hpp).
-#include "kernels.hpp"
+#include "kernels_fast.hpp"
 #include "launch.hpp"
 
 namespace eccx {
@@ -14,9 +14,18 @@ hipError_t base_(int grid, hipStream_t s, size_t n, const uint8_t* scalars, cons
   hipLaunchKernelGGL(k_scalarmul_base<P256>, dim3(grid), dim3(WG), 0, s, n, scalars, table, out, flags, proj, opts);
   return hipGetLastError();
 }
+hipError_t var_fast_(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint8_t* points, uint32_t* jac,
+                     uint8_t* flags, uint32_t* scratch, uint32_t opts) {
+  hipLaunchKernelGGL(k_scalarmul_var_fast<P256>, dim3(grid), dim3(WG), 0, s, n, scalars, points, jac, flags, scratch, opts);
+  return hipGetLastError();
+}
+hipError_t to_affine_jac_(int grid, hipStream_t s, size_t n, const uint32_t* jac, uint8_t* out, uint8_t* flags) {
+  hipLaunchKernelGGL((k_batch_to_affine<P256, true, TO_AFFINE_U>), dim3(grid), dim3(WG), 0, s, n, jac, out, flags);
+  return hipGetLastError();
+}
 }  // namespace
 const CurveOps& ops_P256() {
-  static const CurveOps o = {{P256::FB, P256::SB, P256::L, 2 * P256::L, row_words<P256::L>(), 0}, var_, base_};
+  static const CurveOps o = {{P256::FB, P256::SB, P256::L, 2 * P256::L, row_words<P256::L>(), 0, row5_words<P256::L>(), row_words<P256::L>()}, var_, base_, var_fast_, to_affine_jac_};
   return o;
 }
 }  // namespace eccx

@@ -1,0 +1,247 @@
+// Default (fast) variable-base kernels: Jacobian ladder + batched normalisation.
+//
+//   k_scalarmul_var_fast<C>  same contract as k_scalarmul_var<C> (kernels.hpp) -- the
+//       reference's &Point * &Scalar, src/curve/fiat/curve_macros.rs:321-327 -- but on
+//       Jacobian coordinates (curve_fast.hpp).  Same 4-bit fixed window and digit order as
+//       scalar_mul_fixed_window (src/curve/projective.rs:871-896): table d*P, d = 1..15, then
+//       per nibble (MSB first) 4 doublings + 1 addition.  Writes the un-normalised Jacobian
+//       result per unit; flags[i] = 2 for rejected inputs, 0 otherwise.
+//   k_batch_to_affine<C>     Point::to_affine (projective.rs:655-682) for a whole batch: each
+//       lane normalises U units with ONE field inversion (Montgomery's trick), so the
+//       ~380-multiplication Fermat inversion is paid once per 8 units instead of per unit.
+//
+// Cases the Jacobian addition does not cover are patched per lane after the generic
+// formulas ran: accumulator at infinity -> take the table entry; digit 0 (or an entry at
+// infinity) -> keep the accumulator; equal x and opposite y -> infinity; equal points ->
+// the lane keeps its accumulator and the wavefront runs one extra doubling step (the loop
+// holds a single doubling body and a single addition body, like kernels.hpp).
+#pragma once
+#include "curve_fast.hpp"
+#include "kernels.hpp"
+
+namespace eccx {
+
+template <int L>
+constexpr int row5_words() { return ((5 * L + 3) / 4) * 4; }
+
+template <class C>
+ECCX_DEV void entry_store(uint32_t* __restrict__ row, const JacEntry<C>& p) {
+  constexpr int L = C::L;
+  constexpr int W = row5_words<L>();
+  uint32_t w[W];
+#pragma unroll
+  for (int i = 0; i < L; ++i) {
+    w[i] = p.x.v[i]; w[L + i] = p.y.v[i]; w[2 * L + i] = p.z.v[i]; w[3 * L + i] = p.zz.v[i]; w[4 * L + i] = p.zzz.v[i];
+  }
+#pragma unroll
+  for (int i = 5 * L; i < W; ++i) w[i] = 0;
+  uint4* dst = reinterpret_cast<uint4*>(row);
+#pragma unroll
+  for (int i = 0; i < W / 4; ++i) dst[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+
+template <class C>
+ECCX_DEV void entry_load(JacEntry<C>& p, const uint32_t* __restrict__ row) {
+  constexpr int L = C::L;
+  constexpr int W = row5_words<L>();
+  uint32_t w[W];
+  const uint4* src = reinterpret_cast<const uint4*>(row);
+#pragma unroll
+  for (int i = 0; i < W / 4; ++i) {
+    uint4 q = src[i];
+    w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
+  }
+#pragma unroll
+  for (int i = 0; i < L; ++i) {
+    p.x.v[i] = w[i]; p.y.v[i] = w[L + i]; p.z.v[i] = w[2 * L + i]; p.zz.v[i] = w[3 * L + i]; p.zzz.v[i] = w[4 * L + i];
+  }
+}
+
+template <class C>
+__global__ void __launch_bounds__(WG) k_scalarmul_var_fast(size_t n, const uint8_t* __restrict__ scalars,
+                                                           const uint8_t* __restrict__ points,
+                                                           uint32_t* __restrict__ jac_out, uint8_t* __restrict__ flags,
+                                                           uint32_t* __restrict__ scratch, uint32_t opts) {
+  constexpr int L = C::L;
+  constexpr int FB = C::FB;
+  constexpr int SB = C::SB;
+  constexpr int NW = 2 * SB;
+  constexpr int W5 = row5_words<L>();
+  constexpr int W3 = row_words<L>();
+  // per-lane window table: [workgroup][entry 1..15][thread][W5 words] (entry 0 unused)
+  uint32_t* slab = scratch + ((size_t)blockIdx.x * 16 * WG + threadIdx.x) * (size_t)W5;
+  auto row = [&](uint32_t e) { return slab + (size_t)e * WG * W5; };
+  for (size_t base = (size_t)blockIdx.x * WG; base < n; base += (size_t)gridDim.x * WG) {
+    const size_t gid = base + threadIdx.x;
+    const bool active = gid < n;
+    const size_t idx = active ? gid : n - 1;
+
+    Jac<C> q;
+    bool rejected = false;
+    if (opts & OPT_BASE_IS_GENERATOR) {
+      fe_set<C>(q.x, C::GX);
+      fe_set<C>(q.y, C::GY);
+    } else {
+      Fe<L> rx, ry;
+      fe_load_be<C>(rx, points + idx * (size_t)(2 * FB));
+      fe_load_be<C>(ry, points + idx * (size_t)(2 * FB) + FB);
+      fe_to_mont<C>(q.x, rx);
+      fe_to_mont<C>(q.y, ry);
+      if (opts & OPT_VALIDATE) {
+        rejected = !(fe_is_canonical<C>(rx) && fe_is_canonical<C>(ry) && on_curve<C>(q.x, q.y));
+      }
+    }
+    fe_set<C>(q.z, C::ONE);
+    {
+      JacEntry<C> e1;
+      e1.x = q.x; e1.y = q.y; e1.z = q.z; e1.zz = q.z; e1.zzz = q.z;
+      entry_store<C>(row(1), e1);
+    }
+    const uint8_t* __restrict__ k = scalars + idx * (size_t)SB;
+
+    int b = 0;            // table-build step: 0 -> T[2] = 2P, 1..13 -> T[b+2] = T[b+1] + P
+    int win = 0, sub = 0; // main loop position
+    bool fix_pending = false, fix_lane = false;
+    for (;;) {
+      const bool building = b < 14;
+      if (!building && win == NW) break;
+      const bool do_dbl = fix_pending || (building ? (b == 0) : (sub < 4));
+      bool step_done;
+      if (do_dbl) {
+        Jac<C> t;
+        jac_dbl<C>(t, q);
+        if (fix_pending) {
+          jac_select<C>(q, fix_lane, t, q);
+          fix_pending = false;
+          fix_lane = false;
+        } else {
+          q = t;
+        }
+        step_done = true;
+      } else {
+        uint32_t d = 1;
+        if (!building) {
+          uint32_t byte = k[win >> 1];
+          d = (win & 1) ? (byte & 0x0f) : (byte >> 4);
+        }
+        JacEntry<C> e;
+        entry_load<C>(e, row(d ? d : 1));
+        const bool q_inf = fe_is_zero<C>(q.z);
+        const bool e_skip = (d == 0) || fe_is_zero<C>(e.z);
+        Jac<C> sum;
+        bool hz, rz;
+        jac_add_raw<C>(sum, hz, rz, q, e);
+        const bool same_x = hz && !q_inf && !e_skip;
+        fix_lane = same_x && rz;           // q == e: needs a doubling
+        const bool to_inf = same_x && !rz; // q == -e
+        if (to_inf) fe_zero<C>(sum.z);
+        Jac<C> ej;
+        ej.x = e.x; ej.y = e.y; ej.z = e.z;
+        jac_select<C>(sum, q_inf, ej, sum);
+        jac_select<C>(q, e_skip || fix_lane, q, sum);
+        fix_pending = __builtin_amdgcn_ballot_w64(fix_lane) != 0;
+        step_done = !fix_pending;
+      }
+      if (step_done) {
+        if (building) {
+          JacEntry<C> e;
+          e.x = q.x; e.y = q.y; e.z = q.z;
+          fe_sqr<C>(e.zz, q.z);
+          fe_mul<C>(e.zzz, e.zz, q.z);
+          entry_store<C>(row(b + 2), e);
+          if (++b == 14) fe_zero<C>(q.z);  // accumulator starts at infinity
+        } else if (sub < 4) {
+          ++sub;
+        } else {
+          sub = 0;
+          ++win;
+        }
+      }
+    }
+    if (active) {
+      uint32_t* o = jac_out + idx * (size_t)W3;
+      Pt<C> res;
+      res.x = q.x; res.y = q.y; res.z = q.z;
+      row_store<C>(o, res);
+      flags[idx] = rejected ? 2 : 0;
+    }
+  }
+}
+
+// Normalise a batch of un-normalised points (rows of W3 words: X, Y, Z Montgomery limbs).
+//   JACOBIAN: x = X/Z^2, y = Y/Z^3 ; else homogeneous x = X/Z, y = Y/Z (projective.rs:655-682).
+// flags[i] on entry: 2 marks a rejected input (kept, zero output); on exit 1 marks infinity.
+// Thread t of a workgroup handles units tile + u*WG + t, u = 0..U-1, with one inversion.
+template <class C, bool JACOBIAN, int U>
+__global__ void __launch_bounds__(WG) k_batch_to_affine(size_t n, const uint32_t* __restrict__ pts,
+                                                        uint8_t* __restrict__ out, uint8_t* __restrict__ flags) {
+  constexpr int L = C::L;
+  constexpr int FB = C::FB;
+  constexpr int W3 = row_words<L>();
+  const size_t tile_units = (size_t)WG * U;
+  for (size_t tile = (size_t)blockIdx.x * tile_units; tile < n; tile += (size_t)gridDim.x * tile_units) {
+    Fe<L> pre[U];  // prefix products of the (substituted) Z values
+    Fe<L> one;
+    fe_set<C>(one, C::ONE);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t i = tile + (size_t)u * WG + threadIdx.x;
+      Fe<L> z = one;
+      if (i < n) {
+        const uint32_t* r = pts + i * (size_t)W3 + 2 * L;
+#pragma unroll
+        for (int j = 0; j < L; ++j) z.v[j] = r[j];
+        if (fe_is_zero<C>(z)) z = one;  // z_inverse_ct substitutes 1 (projective.rs:655-659)
+      }
+      if (u == 0) pre[0] = z;
+      else fe_mul<C>(pre[u], pre[u - 1], z);
+    }
+    Fe<L> inv;
+    fe_inv<C>(inv, pre[U - 1]);
+#pragma unroll
+    for (int u = U - 1; u >= 0; --u) {
+      const size_t i = tile + (size_t)u * WG + threadIdx.x;
+      Fe<L> x = one, y = one, z = one;
+      bool present = false;
+      if (i < n) {
+        const uint32_t* r = pts + i * (size_t)W3;
+#pragma unroll
+        for (int j = 0; j < L; ++j) { x.v[j] = r[j]; y.v[j] = r[L + j]; z.v[j] = r[2 * L + j]; }
+        present = !fe_is_zero<C>(z);
+        if (!present) z = one;
+      }
+      Fe<L> zi;
+      if (u > 0) {
+        fe_mul<C>(zi, inv, pre[u - 1]);
+        fe_mul<C>(inv, inv, z);
+      } else {
+        zi = inv;
+      }
+      Fe<L> ax, ay;
+      if constexpr (JACOBIAN) {
+        Fe<L> zi2;
+        fe_sqr<C>(zi2, zi);
+        fe_mul<C>(ax, x, zi2);
+        fe_mul<C>(zi2, zi2, zi);
+        fe_mul<C>(ay, y, zi2);
+      } else {
+        fe_mul<C>(ax, x, zi);
+        fe_mul<C>(ay, y, zi);
+      }
+      if (i < n) {
+        const bool rejected = flags[i] == 2;
+        const bool ok = present && !rejected;
+        Fe<L> t;
+        fe_from_mont<C>(t, ax);
+        if (!ok) fe_zero<C>(t);
+        fe_store_be<C>(out + i * (size_t)(2 * FB), t);
+        fe_from_mont<C>(t, ay);
+        if (!ok) fe_zero<C>(t);
+        fe_store_be<C>(out + i * (size_t)(2 * FB) + FB, t);
+        flags[i] = rejected ? 2 : (present ? 0 : 1);
+      }
+    }
+  }
+}
+
+}  // namespace eccx

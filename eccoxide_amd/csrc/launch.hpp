@@ -12,8 +12,10 @@ struct CurveInfo {
   int sb;           // scalar bytes
   int limbs;        // 32-bit limbs per field element
   int table_words;  // words per comb-table entry (2L Weierstrass, 3L Edwards)
-  int row_words;    // words per variable-base scratch row (0: no scratch)
+  int row_words;    // words per variable-base scratch row, mirror kernels (0: no scratch)
   int edwards;
+  int row5_words;   // words per scratch row of the fast (Jacobian) kernel; 0: no fast path
+  int jac_words;    // words per un-normalised result row (X, Y, Z)
 };
 
 struct CurveOps {
@@ -23,7 +25,12 @@ struct CurveOps {
                     uint8_t* flags, uint8_t* proj, uint32_t* scratch, uint32_t opts);
   hipError_t (*base)(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint32_t* table, uint8_t* out,
                      uint8_t* flags, uint8_t* proj, uint32_t opts);
+  // fast path (may be null): Jacobian ladder into `jac`, then batched normalisation
+  hipError_t (*var_fast)(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint8_t* points,
+                         uint32_t* jac, uint8_t* flags, uint32_t* scratch, uint32_t opts);
+  hipError_t (*to_affine_jac)(int grid, hipStream_t s, size_t n, const uint32_t* jac, uint8_t* out, uint8_t* flags);
 };
+constexpr int TO_AFFINE_U = 8;  // units normalised per lane with one inversion
 
 const CurveOps& ops_P256();
 const CurveOps& ops_P384();

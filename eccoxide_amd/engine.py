@@ -14,6 +14,7 @@ CURVE_IDS = {"p256r1": P256R1, "p384r1": P384R1, "p521r1": P521R1, "bls12_381_g1
 CURVE_NAMES = {v: k for k, v in CURVE_IDS.items()}
 
 VALIDATE_POINTS = 1 << 0
+MIRROR_REFERENCE = 1 << 1
 FLAG_FINITE, FLAG_INFINITY, FLAG_REJECTED = 0, 1, 2
 
 
@@ -83,8 +84,9 @@ class Engine:
 
     # ---- host buffers ------------------------------------------------------
     def scalarmul_var(self, curve, scalars: bytes, points: bytes, *, validate: bool = False,
-                      want_proj: bool = False):
-        """out[i] = scalars[i] * points[i]; returns (affine bytes, flags[, proj bytes])."""
+                      want_proj: bool = False, mirror: bool = False):
+        """out[i] = scalars[i] * points[i]; returns (affine bytes, flags[, proj bytes]).
+        mirror=True (implied by want_proj) runs the reference-mirroring kernels."""
         cid = curve_id(curve)
         sb, fb = scalar_bytes(cid), field_bytes(cid)
         if len(scalars) % sb:
@@ -96,7 +98,7 @@ class Engine:
         flags = ctypes.create_string_buffer(max(1, n))
         proj = ctypes.create_string_buffer(max(1, n * _proj_width(cid))) if want_proj else None
         rc = self._lib.eccx_scalarmul_var(self._ctx, cid, n, scalars, points, out, flags, proj,
-                                          VALIDATE_POINTS if validate else 0)
+                                          (VALIDATE_POINTS if validate else 0) | (MIRROR_REFERENCE if mirror else 0))
         self._check(rc)
         res = (out.raw[: n * 2 * fb], flags.raw[:n])
         return res + (proj.raw[: n * _proj_width(cid)],) if want_proj else res
@@ -126,7 +128,7 @@ class Engine:
 
     # ---- device tensors (torch.uint8, resident on this engine's GPU) -----------
     def scalarmul_var_t(self, curve, scalars, points, out=None, flags=None, proj=None, *,
-                        validate: bool = False, stream: Optional[int] = None):
+                        validate: bool = False, mirror: bool = False, stream: Optional[int] = None):
         """Device-resident variant: tensors are torch.uint8 CUDA tensors; the launch is
         enqueued on `stream` (raw hipStream_t handle; default: torch's current stream)."""
         import torch
@@ -146,7 +148,8 @@ class Engine:
         rc = self._lib.eccx_scalarmul_var_dev(self._ctx, cid, n, scalars.data_ptr(), points.data_ptr(),
                                               out.data_ptr(), flags.data_ptr(),
                                               proj.data_ptr() if proj is not None else None,
-                                              VALIDATE_POINTS if validate else 0, stream)
+                                              (VALIDATE_POINTS if validate else 0) | (MIRROR_REFERENCE if mirror else 0),
+                                              stream)
         self._check(rc)
         return out, flags
 

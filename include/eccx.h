@@ -65,9 +65,17 @@ enum {
 
 /* option bits */
 enum {
-  ECCX_VALIDATE_POINTS = 1u << 0 /* reject input points that are non-canonical or off the curve
-                                    (PointAffine::from_coordinate, src/curve/affine.rs:90-119):
-                                    flag 2, zero output */
+  ECCX_VALIDATE_POINTS = 1u << 0, /* reject input points that are non-canonical or off the curve
+                                     (PointAffine::from_coordinate, src/curve/affine.rs:90-119):
+                                     flag 2, zero output */
+  ECCX_MIRROR_REFERENCE = 1u << 1 /* run the kernels that follow the reference operation for
+                                     operation (RCB complete formulas in homogeneous coordinates,
+                                     src/curve/projective.rs:340-423,586-646).  Implied when `proj`
+                                     is requested.  The default kernels use Jacobian coordinates:
+                                     same affine bytes and flags for every on-curve input, about
+                                     1.5x faster.  Off-curve inputs (only reachable without
+                                     ECCX_VALIDATE_POINTS) give unspecified output by default and
+                                     the reference's arithmetic under this option. */
 };
 
 /* flag values written per unit */

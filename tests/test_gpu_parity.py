@@ -44,10 +44,15 @@ def test_var_matches_oracle(engine, oracle, curve, n):
     ks = W.random_scalars(curve, n, seed=100 + n).tobytes()
     pts = bases(oracle, curve, n, seed=200 + n)
     want_out, want_inf, want_proj = oracle.var(curve, ks, pts, threads=16)
+    # reference-mirroring kernels: bytes, flags and the un-normalised (X:Y:Z[:T]) residues
     out, flags, proj = engine.scalarmul_var(curve, ks, pts, want_proj=True)
     assert out == want_out
     assert flags == want_inf
-    assert proj == want_proj  # same un-normalised (X:Y:Z[:T]) residues as the reference algorithm
+    assert proj == want_proj
+    # default (fast, Jacobian) kernels: same affine bytes and flags
+    out, flags = engine.scalarmul_var(curve, ks, pts)
+    assert out == want_out
+    assert flags == want_inf
 
 
 @pytest.mark.parametrize("curve", ALL)
@@ -82,6 +87,8 @@ def test_edge_scalars(engine, oracle, curve):
     want = oracle.var(curve, ks, pts)
     got = engine.scalarmul_var(curve, ks, pts, want_proj=True)
     assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2]
+    fast = engine.scalarmul_var(curve, ks, pts)
+    assert fast[0] == want[0] and fast[1] == want[1]
     # k = 0 and k = n give the neutral element
     assert got[1][0] == 1 and got[1][vals.index(order)] == 1
     if curve != "ed25519":
@@ -91,6 +98,47 @@ def test_edge_scalars(engine, oracle, curve):
     assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2]
     # 1 * G == G
     assert got[0][2 * fb: 4 * fb] == g
+
+
+# ---- inputs that hit the special cases of the fast (Jacobian) ladder ---------------------------
+@pytest.mark.parametrize("curve", WEI)
+def test_fast_ladder_exceptional_cases(engine, oracle, curve):
+    """The complete formulas of the reference have no special cases; the Jacobian ladder
+    does.  Scalars built so that the accumulator meets the table entry:
+      k = n + 2d with d = -n mod 16: before the last addition the accumulator is
+          ((n+d)/16)*16*P = d*P and the digit is d         -> P + P (doubling) case
+      k = n: accumulator (n-d)*P, digit d                   -> P + (-P) case
+      k = 16^j * small, k with zero nibbles                 -> infinity / digit-0 cases
+    """
+    fb, sb = sizes(curve)
+    order = W.order(curve)
+    d = (-order) % 16
+    assert d != 0
+    vals = [order + 2 * d, order, order + 1, order + 16, 1 << 4, 1 << 8, (1 << 12) + 1, 0x1001 << 64,
+            2 * order + 4 * d if 2 * order + 4 * d < (1 << (8 * sb)) else order + 2 * d]
+    if curve == "p521r1":
+        vals += [(order + 2 * d) * 16 + 5, (order + 2 * d) * 256 + 0x50]
+    vals = [v for v in vals if v < (1 << (8 * sb))]
+    n = len(vals)
+    ks = b"".join(v.to_bytes(sb, "big") for v in vals)
+    pts = bases(oracle, curve, n, seed=31)
+    want = oracle.var(curve, ks, pts)
+    got = engine.scalarmul_var(curve, ks, pts)
+    assert got[0] == want[0] and got[1] == want[1]
+    got = engine.scalarmul_var(curve, ks, pts, mirror=True)
+    assert got[0] == want[0] and got[1] == want[1]
+
+
+def test_fast_ladder_small_order_point_bls(engine, oracle):
+    """(0, 2) is a point of order 3 on y^2 = x^3 + 4 (outside G1): 2P = -P, 3P = infinity, so
+    the window-table build itself runs into P + (-P), infinity + P and P + P."""
+    n = 64
+    ks = W.random_scalars("bls12_381_g1", n, seed=41).tobytes()
+    pt = (0).to_bytes(48, "big") + (2).to_bytes(48, "big")
+    want = oracle.var("bls12_381_g1", ks, pt * n)
+    got = engine.scalarmul_var("bls12_381_g1", ks, pt * n)
+    assert got[0] == want[0] and got[1] == want[1]
+    assert set(want[1]) <= {0, 1} and 1 in set(want[1])   # k = 0 mod 3 gives infinity
 
 
 # ---- the reference's own known-answer vectors, on the GPU ---------------------------------
