@@ -28,13 +28,20 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+def _var_muls(nw, dbl, inv):
+    """field mul+sqr the default (Jacobian) variable-base path issues per unit: window table
+    (1 doubling + 13 additions + Z^2, Z^3 per entry), nw windows of 4 doublings + 1 addition,
+    input conversion, and the batched normalisation (one Fermat inversion per 8 units)."""
+    return (dbl + 13 * 14 + 14 * 2) + nw * (4 * dbl + 14) + 2 + (inv + 7) // 8 + 9
+
+
 WORKLOADS = {
     # name: (curve, op, per-GPU batch, algorithmic bytes per unit, field mul+sqr per unit, MACs per field mul)
-    "p256r1_var_2^20": ("p256r1", "var", 1 << 20, 160, 257 * 13 + 77 * 14, 8 * 8 + 8 * 5),
-    "ed25519_base_2^20": ("ed25519", "base", 1 << 20, 96, 64 * 9, 2 * 8 * 8),
-    "p384r1_var_2^19": ("p384r1", "var", 1 << 19, 240, 385 * 13 + 109 * 14, 12 * 12 + 12 * 10),
-    "p521r1_var_2^19": ("p521r1", "var", 1 << 19, 330, 529 * 13 + 145 * 14, 2 * 17 * 17),
-    "bls12_381_g1_var_2^20": ("bls12_381_g1", "var", 1 << 20, 224, 257 * 9 + 77 * 14, 2 * 12 * 12),
+    "p256r1_var_2^20": ("p256r1", "var", 1 << 20, 160, _var_muls(64, 8, 383), 8 * 8 + 8 * 5),
+    "ed25519_base_2^20": ("ed25519", "base", 1 << 20, 96, 64 * 9 + (380 + 7) // 8 + 7, 2 * 8 * 8),
+    "p384r1_var_2^19": ("p384r1", "var", 1 << 19, 240, _var_muls(96, 8, 575), 12 * 12 + 12 * 10),
+    "p521r1_var_2^19": ("p521r1", "var", 1 << 19, 330, _var_muls(132, 8, 780), 2 * 17 * 17),
+    "bls12_381_g1_var_2^20": ("bls12_381_g1", "var", 1 << 20, 224, _var_muls(64, 7, 570), 2 * 12 * 12),
 }
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # v_mad_u64_u32 issue peak measured by tools/ubench/valu_rates.hip on MI355X

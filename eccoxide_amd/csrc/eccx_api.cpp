@@ -26,6 +26,7 @@ constexpr int NCURVES = 5;
 constexpr uint32_t K_BASE_IS_GENERATOR = 1u << 0;
 constexpr uint32_t K_OUT_TABLE = 1u << 1;
 constexpr uint32_t K_VALIDATE = 1u << 2;
+constexpr uint32_t K_OUT_ROWS = 1u << 3;
 
 const CurveOps* ops_of(int curve) {
   switch (curve) {
@@ -94,6 +95,18 @@ int ensure_scratch(eccx_ctx* ctx, int row_words, int grid) {
   return ensure_buffer(ctx, &ctx->scratch, &ctx->scratch_words, words);
 }
 
+// buffer of un-normalised result rows (X, Y, Z limbs) for the batched normalisation
+int ensure_rows(eccx_ctx* ctx, const CurveOps* ops, size_t n) {
+  std::lock_guard<std::mutex> g(ctx->scratch_mu);
+  return ensure_buffer(ctx, &ctx->jac, &ctx->jac_words, n * (size_t)ops->info.jac_words);
+}
+
+int norm_grid(const eccx_ctx* ctx, size_t n) {
+  size_t tile = (size_t)eccx::LAUNCH_WG * eccx::TO_AFFINE_U;
+  size_t tiles = (n + tile - 1) / tile;
+  return (int)std::max<size_t>(1, std::min(tiles, (size_t)ctx->cus * 4));
+}
+
 // Variable base.  mirror = run the reference-mirroring kernel (homogeneous RCB formulas,
 // un-normalised X:Y:Z available); otherwise the fast Jacobian kernel + batched
 // normalisation where the curve has one.
@@ -105,20 +118,24 @@ int launch_var(eccx_ctx* ctx, const CurveOps* ops, size_t n, const uint8_t* d_sc
   if (fast) {
     int rc = ensure_scratch(ctx, ops->info.row5_words, grid);
     if (rc) return rc;
-    {
-      std::lock_guard<std::mutex> g(ctx->scratch_mu);
-      rc = ensure_buffer(ctx, &ctx->jac, &ctx->jac_words, n * (size_t)ops->info.jac_words);
-      if (rc) return rc;
-    }
+    rc = ensure_rows(ctx, ops, n);
+    if (rc) return rc;
     HIP_TRY(ctx, ops->var_fast(grid, s, n, d_scalars, d_points, ctx->jac, d_flags, ctx->scratch, kopts));
-    size_t tiles = (n + (size_t)eccx::LAUNCH_WG * eccx::TO_AFFINE_U - 1) / ((size_t)eccx::LAUNCH_WG * eccx::TO_AFFINE_U);
-    int g2 = (int)std::max<size_t>(1, std::min(tiles, (size_t)ctx->cus * 4));
-    HIP_TRY(ctx, ops->to_affine_jac(g2, s, n, ctx->jac, d_out, d_flags));
+    HIP_TRY(ctx, ops->to_affine_jac(norm_grid(ctx, n), s, n, ctx->jac, d_out, d_flags));
     return ECCX_OK;
   }
   if (ops->info.row_words) {
     int rc = ensure_scratch(ctx, ops->info.row_words, grid);
     if (rc) return rc;
+  }
+  if (!d_proj && !(kopts & K_OUT_TABLE) && ops->to_affine_hom) {
+    // un-normalised rows, then one inversion per TO_AFFINE_U units
+    int rc = ensure_rows(ctx, ops, n);
+    if (rc) return rc;
+    HIP_TRY(ctx, ops->var(grid, s, n, d_scalars, d_points, reinterpret_cast<uint8_t*>(ctx->jac), d_flags, nullptr,
+                          ctx->scratch, kopts | K_OUT_ROWS));
+    HIP_TRY(ctx, ops->to_affine_hom(norm_grid(ctx, n), s, n, ctx->jac, d_out, d_flags));
+    return ECCX_OK;
   }
   HIP_TRY(ctx, ops->var(grid, s, n, d_scalars, d_points, d_out, d_flags, d_proj, ctx->scratch, kopts));
   return ECCX_OK;
@@ -317,6 +334,16 @@ int eccx_scalarmul_base_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_sc
   hipStream_t s = static_cast<hipStream_t>(stream);  // NULL = HIP's default stream
   size_t need = (n + eccx::LAUNCH_WG - 1) / eccx::LAUNCH_WG;
   int grid = (int)std::max<size_t>(1, std::min(need, (size_t)ctx->cus * 8));
+  if (!d_proj && ops->to_affine_hom) {
+    rc = ensure_rows(ctx, ops, n);
+    if (rc) return rc;
+    HIP_TRY(ctx, ops->base(grid, s, n, static_cast<const uint8_t*>(d_scalars), ctx->comb[curve],
+                           reinterpret_cast<uint8_t*>(ctx->jac), static_cast<uint8_t*>(d_flags), nullptr,
+                           K_OUT_ROWS));
+    HIP_TRY(ctx, ops->to_affine_hom(norm_grid(ctx, n), s, n, ctx->jac, static_cast<uint8_t*>(d_out),
+                                    static_cast<uint8_t*>(d_flags)));
+    return ECCX_OK;
+  }
   HIP_TRY(ctx, ops->base(grid, s, n, static_cast<const uint8_t*>(d_scalars), ctx->comb[curve],
                          static_cast<uint8_t*>(d_out), static_cast<uint8_t*>(d_flags),
                          static_cast<uint8_t*>(d_proj), 0u));

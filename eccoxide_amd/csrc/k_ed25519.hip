@@ -1,5 +1,5 @@
 // Kernel instantiations for edwards25519 (see kernels.hpp).
-#include "kernels.hpp"
+#include "kernels_fast.hpp"
 #include "launch.hpp"
 
 namespace eccx {
@@ -14,9 +14,13 @@ hipError_t base_(int grid, hipStream_t s, size_t n, const uint8_t* scalars, cons
   hipLaunchKernelGGL(k_ed_scalarmul_base<ED25519>, dim3(grid), dim3(WG), 0, s, n, scalars, table, out, flags, proj, opts);
   return hipGetLastError();
 }
+hipError_t to_affine_hom_(int grid, hipStream_t s, size_t n, const uint32_t* rows, uint8_t* out, uint8_t* flags) {
+  hipLaunchKernelGGL((k_batch_to_affine<ED25519, NORM_EDWARDS, TO_AFFINE_U>), dim3(grid), dim3(WG), 0, s, n, rows, out, flags);
+  return hipGetLastError();
+}
 }  // namespace
 const CurveOps& ops_ED25519() {
-  static const CurveOps o = {{ED25519::FB, ED25519::SB, ED25519::L, 3 * ED25519::L, 0, 1, 0, 0}, var_, base_, nullptr, nullptr};
+  static const CurveOps o = {{ED25519::FB, ED25519::SB, ED25519::L, 3 * ED25519::L, 0, 1, 0, row_words<ED25519::L>()}, var_, base_, nullptr, nullptr, to_affine_hom_};
   return o;
 }
 }  // namespace eccx

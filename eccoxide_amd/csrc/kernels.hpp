@@ -29,6 +29,8 @@ enum : uint32_t {
   OPT_BASE_IS_GENERATOR = 1u << 0,  // ignore `points`, use the curve generator
   OPT_OUT_TABLE = 1u << 1,          // write affine Montgomery limbs (comb-table rows) instead of bytes
   OPT_VALIDATE = 1u << 2,           // reject non-canonical / off-curve input points (flag 2)
+  OPT_OUT_ROWS = 1u << 3,           // write the un-normalised result as a row of Montgomery limbs
+                                    // (X, Y, Z) for k_batch_to_affine instead of normalising here
 };
 
 constexpr int WG = 256;
@@ -103,6 +105,11 @@ ECCX_DEV void store_result(size_t idx, const Pt<C>& q, bool rejected, uint8_t* _
                            uint8_t* __restrict__ flags, uint8_t* __restrict__ proj, uint32_t opts) {
   constexpr int L = C::L;
   constexpr int FB = C::FB;
+  if (opts & OPT_OUT_ROWS) {
+    row_store<C>(reinterpret_cast<uint32_t*>(out) + idx * (size_t)row_words<L>(), q);
+    flags[idx] = rejected ? 2 : 0;
+    return;
+  }
   Fe<L> ax, ay, t;
   bool present = to_affine<C>(ax, ay, q);
   if (opts & OPT_OUT_TABLE) {
@@ -243,6 +250,13 @@ template <class C>
 ECCX_DEV void ed_store_result(size_t idx, const EdPt<C>& q, bool rejected, uint8_t* __restrict__ out,
                               uint8_t* __restrict__ flags, uint8_t* __restrict__ proj, uint32_t opts) {
   constexpr int L = C::L;
+  if (opts & OPT_OUT_ROWS) {
+    Pt<C> row;
+    row.x = q.x; row.y = q.y; row.z = q.z;
+    row_store<C>(reinterpret_cast<uint32_t*>(out) + idx * (size_t)row_words<L>(), row);
+    flags[idx] = rejected ? 2 : 0;
+    return;
+  }
   Fe<L> zi, ax, ay, t, one;
   fe_inv<C>(zi, q.z);  // Z != 0 on a complete Edwards curve (curve25519.rs:663-666)
   fe_mul<C>(ax, q.x, zi);

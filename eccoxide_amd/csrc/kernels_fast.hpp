@@ -169,10 +169,14 @@ __global__ void __launch_bounds__(WG) k_scalarmul_var_fast(size_t n, const uint8
 }
 
 // Normalise a batch of un-normalised points (rows of W3 words: X, Y, Z Montgomery limbs).
-//   JACOBIAN: x = X/Z^2, y = Y/Z^3 ; else homogeneous x = X/Z, y = Y/Z (projective.rs:655-682).
+//   MODE 0: homogeneous x = X/Z, y = Y/Z, big-endian bytes (projective.rs:655-682)
+//   MODE 1: Jacobian x = X/Z^2, y = Y/Z^3, big-endian bytes
+//   MODE 2: edwards25519: x = X/Z, y = Y/Z, little-endian bytes, flag 1 = neutral element
+//           (curve25519.rs:663-666; Z is never 0 on a complete Edwards curve)
 // flags[i] on entry: 2 marks a rejected input (kept, zero output); on exit 1 marks infinity.
 // Thread t of a workgroup handles units tile + u*WG + t, u = 0..U-1, with one inversion.
-template <class C, bool JACOBIAN, int U>
+enum { NORM_HOMOGENEOUS = 0, NORM_JACOBIAN = 1, NORM_EDWARDS = 2 };
+template <class C, int MODE, int U>
 __global__ void __launch_bounds__(WG) k_batch_to_affine(size_t n, const uint32_t* __restrict__ pts,
                                                         uint8_t* __restrict__ out, uint8_t* __restrict__ flags) {
   constexpr int L = C::L;
@@ -218,7 +222,7 @@ __global__ void __launch_bounds__(WG) k_batch_to_affine(size_t n, const uint32_t
         zi = inv;
       }
       Fe<L> ax, ay;
-      if constexpr (JACOBIAN) {
+      if constexpr (MODE == NORM_JACOBIAN) {
         Fe<L> zi2;
         fe_sqr<C>(zi2, zi);
         fe_mul<C>(ax, x, zi2);
@@ -230,15 +234,26 @@ __global__ void __launch_bounds__(WG) k_batch_to_affine(size_t n, const uint32_t
       }
       if (i < n) {
         const bool rejected = flags[i] == 2;
-        const bool ok = present && !rejected;
         Fe<L> t;
-        fe_from_mont<C>(t, ax);
-        if (!ok) fe_zero<C>(t);
-        fe_store_be<C>(out + i * (size_t)(2 * FB), t);
-        fe_from_mont<C>(t, ay);
-        if (!ok) fe_zero<C>(t);
-        fe_store_be<C>(out + i * (size_t)(2 * FB) + FB, t);
-        flags[i] = rejected ? 2 : (present ? 0 : 1);
+        if constexpr (MODE == NORM_EDWARDS) {
+          const bool neutral = fe_is_zero<C>(ax) && fe_eq<C>(ay, one);
+          fe_from_mont<C>(t, ax);
+          if (rejected) fe_zero<C>(t);
+          fe_store_le<C>(out + i * (size_t)(2 * FB), t);
+          fe_from_mont<C>(t, ay);
+          if (rejected) fe_zero<C>(t);
+          fe_store_le<C>(out + i * (size_t)(2 * FB) + FB, t);
+          flags[i] = rejected ? 2 : (neutral ? 1 : 0);
+        } else {
+          const bool ok = present && !rejected;
+          fe_from_mont<C>(t, ax);
+          if (!ok) fe_zero<C>(t);
+          fe_store_be<C>(out + i * (size_t)(2 * FB), t);
+          fe_from_mont<C>(t, ay);
+          if (!ok) fe_zero<C>(t);
+          fe_store_be<C>(out + i * (size_t)(2 * FB) + FB, t);
+          flags[i] = rejected ? 2 : (present ? 0 : 1);
+        }
       }
     }
   }
