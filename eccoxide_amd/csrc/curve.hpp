@@ -119,6 +119,21 @@ ECCX_DEV void ed_add(EdPt<C>& r, const EdPt<C>& p, const EdPt<C>& q) {
   M_(r.x, e, f); M_(r.y, g, h); M_(r.z, f, g); M_(r.t, e, h);
 }
 
+// r = p + (x2, y2) for an affine table entry (Z2 = 1) whose 2d*x2*y2 is precomputed:
+// 7 multiplications (curve25519.rs:712-729 add_cached, with Z2 = 1 folded in).
+template <class C>
+ECCX_DEV void ed_add_cached(EdPt<C>& r, const EdPt<C>& p, const Fe<C::L>& x2, const Fe<C::L>& y2,
+                            const Fe<C::L>& t2d) {
+  using F = Fe<C::L>;
+  F aa, bb, cc, dd, e, f, g, h, u, v;
+  S_(u, p.y, p.x); S_(v, y2, x2); M_(aa, u, v);
+  A_(u, p.y, p.x); A_(v, y2, x2); M_(bb, u, v);
+  M_(cc, p.t, t2d);
+  A_(dd, p.z, p.z);
+  S_(e, bb, aa); S_(f, dd, cc); A_(g, dd, cc); A_(h, bb, aa);
+  M_(r.x, e, f); M_(r.y, g, h); M_(r.z, f, g); M_(r.t, e, h);
+}
+
 template <class C>
 ECCX_DEV void ed_dbl(EdPt<C>& r, const EdPt<C>& p) {
   using F = Fe<C::L>;

@@ -176,8 +176,94 @@ ECCX_DEV void fe_select(Fe<C::L>& r, bool take_a, const Fe<C::L>& a, const Fe<C:
 
 // Montgomery product r = a*b/R mod P, canonical.  Product-scanning with the
 // reduction multiples m[i]*P[j] accumulated in the same column chain.
+// Mersenne prime p = 2^K - 1 (P-521): plain representation, full product then fold
+// (2^K = 1 mod p).  L^2 MACs instead of the 2 L^2 of a Montgomery product.  Stands in for
+// the reference's unsaturated-Solinas fiat_p521_carry_mul (src/curve/fiat/p521_64.rs:297)
+// by value; inputs canonical (< p), output canonical.
+template <class C, bool BCONST>
+ECCX_DEV void fe_mul_mersenne(Fe<C::L>& r, const Fe<C::L>& a, const uint32_t (&b)[C::L]) {
+  constexpr int L = C::L;
+  constexpr int TOPB = C::MERSENNE - 32 * (L - 1);  // bits in the top limb (9 for P-521)
+  constexpr uint32_t TOPMASK = (1u << TOPB) - 1;
+  uint32_t t[2 * L];
+  uint64_t lo = 0;
+  uint32_t hi = 0;
+  MacQ<BCONST> qa;
+#pragma unroll
+  for (int k = 0; k < 2 * L - 1; ++k) {
+#pragma unroll
+    for (int i = (k < L ? 0 : k - L + 1); i <= (k < L ? k : L - 1); ++i) qa.push(lo, hi, a.v[i], b[k - i]);
+    qa.flush(lo, hi);
+    t[k] = (uint32_t)lo;
+    col_shift(lo, hi);
+  }
+  t[2 * L - 1] = (uint32_t)lo;
+  // T = hi * 2^K + lo  ->  lo + hi
+  uint32_t s[L];
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < L; ++i) {
+    uint32_t h = (t[L - 1 + i] >> TOPB) | (t[L + i] << (32 - TOPB));
+    uint32_t l = (i == L - 1) ? (t[i] & TOPMASK) : t[i];
+    s[i] = addc(l, h, c);
+  }
+  // at most one bit above 2^K is left: fold it once more (cannot overflow again)
+  uint32_t top = s[L - 1] >> TOPB;
+  s[L - 1] &= TOPMASK;
+  c = 0;
+  s[0] = addc(s[0], top, c);
+#pragma unroll
+  for (int i = 1; i < L; ++i) s[i] = addc(s[i], 0u, c);
+  cond_sub_p<C>(r, s, 0u);
+}
+
+// p = 2^255 - 19: plain representation, full 8x8 product, then fold with 2^256 = 38 and
+// 2^255 = 19 (mod p).  72 multiply instructions instead of the 128 of a Montgomery product.
+// Stands in for fiat_25519_carry_mul (src/curve/fiat/curve25519_64.rs:217) by value.
+template <class C, bool BCONST>
+ECCX_DEV void fe_mul_pm19(Fe<C::L>& r, const Fe<C::L>& a, const uint32_t (&b)[C::L]) {
+  constexpr int L = C::L;  // 8
+  uint32_t t[2 * L];
+  uint64_t lo = 0;
+  uint32_t hi = 0;
+  MacQ<BCONST> qa;
+#pragma unroll
+  for (int k = 0; k < 2 * L - 1; ++k) {
+#pragma unroll
+    for (int i = (k < L ? 0 : k - L + 1); i <= (k < L ? k : L - 1); ++i) qa.push(lo, hi, a.v[i], b[k - i]);
+    qa.flush(lo, hi);
+    t[k] = (uint32_t)lo;
+    col_shift(lo, hi);
+  }
+  t[2 * L - 1] = (uint32_t)lo;
+  // u = lo + 38 * hi  (no 64-bit overflow: 38 * 2^32 + 2^32 + 2^38 < 2^64)
+  uint32_t u[L];
+  uint64_t acc = 0;
+#pragma unroll
+  for (int i = 0; i < L; ++i) {
+    acc = (uint64_t)t[L + i] * 38u + t[i] + (acc >> 32);
+    u[i] = (uint32_t)acc;
+  }
+  // remaining weight: (acc >> 32) * 2^256 + bit 255 of u  ->  19 * (2c + bit255)
+  uint32_t top = ((uint32_t)(acc >> 32) << 1) | (u[L - 1] >> 31);
+  u[L - 1] &= 0x7fffffffu;
+  uint32_t c = 0;
+  u[0] = addc(u[0], top * 19u, c);
+#pragma unroll
+  for (int i = 1; i < L; ++i) u[i] = addc(u[i], 0u, c);
+  cond_sub_p<C>(r, u, 0u);  // u < 2^255 + 19 * 80 < 2p
+}
+
 template <class C, bool BCONST = false>
 ECCX_DEV void fe_mul_impl(Fe<C::L>& r, const Fe<C::L>& a, const uint32_t (&b)[C::L]) {
+  if constexpr (C::MERSENNE != 0) {
+    fe_mul_mersenne<C, BCONST>(r, a, b);
+    return;
+  }
+  if constexpr (C::PM19 != 0) {
+    fe_mul_pm19<C, BCONST>(r, a, b);
+    return;
+  }
   constexpr int L = C::L;
   uint32_t m[L];
   uint32_t t[L];

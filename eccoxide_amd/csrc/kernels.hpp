@@ -261,11 +261,15 @@ ECCX_DEV void ed_store_result(size_t idx, const EdPt<C>& q, bool rejected, uint8
   fe_inv<C>(zi, q.z);  // Z != 0 on a complete Edwards curve (curve25519.rs:663-666)
   fe_mul<C>(ax, q.x, zi);
   fe_mul<C>(ay, q.y, zi);
-  if (opts & OPT_OUT_TABLE) {  // comb rows: x, y, t = x*y (from_affine, curve25519.rs:638-645)
-    uint32_t* row = reinterpret_cast<uint32_t*>(out) + idx * (size_t)(3 * L);
+  if (opts & OPT_OUT_TABLE) {
+    // comb rows: x, y, t = x*y (from_affine, curve25519.rs:638-645) and 2d*x*y, the operand
+    // the addition would otherwise recompute (the reference's CachedPoint, curve25519.rs:712-729)
+    uint32_t* row = reinterpret_cast<uint32_t*>(out) + idx * (size_t)(4 * L);
+    Fe<L> t2d;
     fe_mul<C>(t, ax, ay);
+    fe_mul_k<C>(t2d, t, C::D2);
 #pragma unroll
-    for (int i = 0; i < L; ++i) { row[i] = ax.v[i]; row[L + i] = ay.v[i]; row[2 * L + i] = t.v[i]; }
+    for (int i = 0; i < L; ++i) { row[i] = ax.v[i]; row[L + i] = ay.v[i]; row[2 * L + i] = t.v[i]; row[3 * L + i] = t2d.v[i]; }
     return;
   }
   fe_set<C>(one, C::ONE);
@@ -341,7 +345,7 @@ __global__ void __launch_bounds__(WG) k_ed_scalarmul_var(size_t n, const uint8_t
   }  // grid-stride
 }
 
-// table[w][d] (d = 1..15): x, y, t = x*y Montgomery limbs, 3L words per entry
+// table[w][d] (d = 1..15): x, y, t = x*y, 2d*x*y limbs, 4L words per entry
 template <class C>
 __global__ void __launch_bounds__(WG) k_ed_scalarmul_base(size_t n, const uint8_t* __restrict__ scalars,
                                                           const uint32_t* __restrict__ table,
@@ -359,12 +363,24 @@ __global__ void __launch_bounds__(WG) k_ed_scalarmul_base(size_t n, const uint8_
     uint32_t byte = k[31 - (w >> 1)];  // indexes the big-endian scalar (curve25519.rs:842-846)
     uint32_t d = (w & 1) ? (byte >> 4) : (byte & 0x0f);
     EdPt<C> sel;
-    const uint32_t* __restrict__ e = table + ((size_t)w * 16 + d) * (3 * L);
+    const uint32_t* __restrict__ e = table + ((size_t)w * 16 + d) * (4 * L);
 #pragma unroll
-    for (int i = 0; i < L; ++i) { sel.x.v[i] = e[i]; sel.y.v[i] = e[L + i]; sel.t.v[i] = e[2 * L + i]; }
-    fe_set<C>(sel.z, C::ONE);
-    if (d == 0) ed_set_identity<C>(sel);
-    ed_add<C>(q, q, sel);
+    for (int i = 0; i < L; ++i) { sel.x.v[i] = e[i]; sel.y.v[i] = e[L + i]; }
+    if (opts & OPT_OUT_ROWS) {
+      // default path: Z2 = 1 and 2d*T2 comes from the table -> 7 multiplications
+      // (same point as Point::add, curve25519.rs:695-710, in other projective coordinates)
+      Fe<L> t2d;
+#pragma unroll
+      for (int i = 0; i < L; ++i) t2d.v[i] = e[3 * L + i];
+      if (d == 0) { fe_zero<C>(sel.x); fe_set<C>(sel.y, C::ONE); fe_zero<C>(t2d); }
+      ed_add_cached<C>(q, q, sel.x, sel.y, t2d);
+    } else {
+#pragma unroll
+      for (int i = 0; i < L; ++i) sel.t.v[i] = e[2 * L + i];
+      fe_set<C>(sel.z, C::ONE);
+      if (d == 0) ed_set_identity<C>(sel);
+      ed_add<C>(q, q, sel);
+    }
   }
   if (active) ed_store_result<C>(idx, q, false, out, flags, proj, opts);
   }  // grid-stride

@@ -62,7 +62,9 @@ def test_engine_side_constants_match_reference():
         c = R.CURVES[name]
         p, L = limbs("P")
         assert p == c.p
-        Rm = 1 << (32 * L)
+        mersenne = int(re.search(r"MERSENNE = (\d+);", body).group(1))
+        Rm = 1 if mersenne else 1 << (32 * L)   # Mersenne fields are kept in plain form
+        assert (mersenne != 0) == (name == "p521r1") and (not mersenne or p == 2**mersenne - 1)
         assert limbs("ONE")[0] == Rm % p and limbs("R2")[0] == Rm * Rm % p
         assert limbs("B")[0] == c.b * Rm % p and limbs("B3")[0] == c.b3 * Rm % p
         assert limbs("GX")[0] == c.gx * Rm % p and limbs("GY")[0] == c.gy * Rm % p
