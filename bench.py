@@ -38,7 +38,8 @@ def _var_muls(nw, dbl, inv):
 WORKLOADS = {
     # name: (curve, op, per-GPU batch, algorithmic bytes per unit, field mul+sqr per unit, MACs per field mul)
     "p256r1_var_2^20": ("p256r1", "var", 1 << 20, 160, _var_muls(64, 8, 383), 8 * 8 + 8 * 5),
-    "ed25519_base_2^20": ("ed25519", "base", 1 << 20, 96, 64 * 9 + (380 + 7) // 8 + 7, 2 * 8 * 8),
+    "ed25519_base_2^20": ("ed25519", "base", 1 << 20, 96, 64 * 7 + 2 + (380 + 7) // 8 + 7, 8 * 8 + 8),
+    "p256r1_base_2^20": ("p256r1", "base", 1 << 20, 96, 64 * 11 + (383 + 7) // 8 + 9, 8 * 8 + 8 * 5),
     "p384r1_var_2^19": ("p384r1", "var", 1 << 19, 240, _var_muls(96, 8, 575), 12 * 12 + 12 * 10),
     "p521r1_var_2^19": ("p521r1", "var", 1 << 19, 330, _var_muls(132, 8, 780), 2 * 17 * 17),
     "bls12_381_g1_var_2^20": ("bls12_381_g1", "var", 1 << 20, 224, _var_muls(64, 7, 570), 2 * 12 * 12),

@@ -84,6 +84,27 @@ ECCX_DEV void jac_add_raw(Jac<C>& r, bool& h_zero, bool& r_zero, const Jac<C>& p
   r.x = x3; r.y = y3; r.z = z3;
 }
 
+// r = p + (x2, y2, 1): mixed addition with an affine operand (11 mul).  Same validity
+// conditions and h_zero / r_zero reporting as jac_add_raw.
+template <class C>
+ECCX_DEV void jac_madd_raw(Jac<C>& r, bool& h_zero, bool& r_zero, const Jac<C>& p, const Fe<C::L>& x2,
+                           const Fe<C::L>& y2) {
+  using F = Fe<C::L>;
+  F z1z1, u2, s2, h, rr, hh, hhh, v, t, x3, y3, z3;
+  Q_(z1z1, p.z);
+  M_(u2, x2, z1z1);
+  M_(t, p.z, z1z1); M_(s2, y2, t);
+  S_(h, u2, p.x);
+  S_(rr, s2, p.y);
+  h_zero = fe_is_zero<C>(h);
+  r_zero = fe_is_zero<C>(rr);
+  Q_(hh, h); M_(hhh, h, hh); M_(v, p.x, hh);
+  Q_(x3, rr); S_(x3, x3, hhh); S_(x3, x3, v); S_(x3, x3, v);
+  S_(t, v, x3); M_(y3, rr, t); M_(t, p.y, hhh); S_(y3, y3, t);
+  M_(z3, p.z, h);
+  r.x = x3; r.y = y3; r.z = z3;
+}
+
 template <class C>
 ECCX_DEV void jac_select(Jac<C>& r, bool take_a, const Jac<C>& a, const Jac<C>& b) {
   fe_select<C>(r.x, take_a, a.x, b.x);

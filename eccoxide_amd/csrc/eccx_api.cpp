@@ -334,6 +334,15 @@ int eccx_scalarmul_base_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_sc
   hipStream_t s = static_cast<hipStream_t>(stream);  // NULL = HIP's default stream
   size_t need = (n + eccx::LAUNCH_WG - 1) / eccx::LAUNCH_WG;
   int grid = (int)std::max<size_t>(1, std::min(need, (size_t)ctx->cus * 8));
+  if (!d_proj && !(opts & ECCX_MIRROR_REFERENCE) && ops->base_fast) {
+    rc = ensure_rows(ctx, ops, n);
+    if (rc) return rc;
+    HIP_TRY(ctx, ops->base_fast(grid, s, n, static_cast<const uint8_t*>(d_scalars), ctx->comb[curve], ctx->jac,
+                                static_cast<uint8_t*>(d_flags)));
+    HIP_TRY(ctx, ops->to_affine_jac(norm_grid(ctx, n), s, n, ctx->jac, static_cast<uint8_t*>(d_out),
+                                    static_cast<uint8_t*>(d_flags)));
+    return ECCX_OK;
+  }
   if (!d_proj && ops->to_affine_hom) {
     rc = ensure_rows(ctx, ops, n);
     if (rc) return rc;

@@ -20,7 +20,7 @@ hipError_t to_affine_hom_(int grid, hipStream_t s, size_t n, const uint32_t* row
 }
 }  // namespace
 const CurveOps& ops_ED25519() {
-  static const CurveOps o = {{ED25519::FB, ED25519::SB, ED25519::L, 4 * ED25519::L, 0, 1, 0, row_words<ED25519::L>()}, var_, base_, nullptr, nullptr, to_affine_hom_};
+  static const CurveOps o = {{ED25519::FB, ED25519::SB, ED25519::L, 4 * ED25519::L, 0, 1, 0, row_words<ED25519::L>()}, var_, base_, nullptr, nullptr, nullptr, to_affine_hom_};
   return o;
 }
 }  // namespace eccx

@@ -23,13 +23,18 @@ hipError_t to_affine_jac_(int grid, hipStream_t s, size_t n, const uint32_t* jac
   hipLaunchKernelGGL((k_batch_to_affine<P384, NORM_JACOBIAN, TO_AFFINE_U>), dim3(grid), dim3(WG), 0, s, n, jac, out, flags);
   return hipGetLastError();
 }
+hipError_t base_fast_(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint32_t* table, uint32_t* jac,
+                      uint8_t* flags) {
+  hipLaunchKernelGGL(k_scalarmul_base_fast<P384>, dim3(grid), dim3(WG), 0, s, n, scalars, table, jac, flags);
+  return hipGetLastError();
+}
 hipError_t to_affine_hom_(int grid, hipStream_t s, size_t n, const uint32_t* rows, uint8_t* out, uint8_t* flags) {
   hipLaunchKernelGGL((k_batch_to_affine<P384, NORM_HOMOGENEOUS, TO_AFFINE_U>), dim3(grid), dim3(WG), 0, s, n, rows, out, flags);
   return hipGetLastError();
 }
 }  // namespace
 const CurveOps& ops_P384() {
-  static const CurveOps o = {{P384::FB, P384::SB, P384::L, 2 * P384::L, row_words<P384::L>(), 0, row5_words<P384::L>(), row_words<P384::L>()}, var_, base_, var_fast_, to_affine_jac_, to_affine_hom_};
+  static const CurveOps o = {{P384::FB, P384::SB, P384::L, 2 * P384::L, row_words<P384::L>(), 0, row5_words<P384::L>(), row_words<P384::L>()}, var_, base_, var_fast_, to_affine_jac_, base_fast_, to_affine_hom_};
   return o;
 }
 }  // namespace eccx

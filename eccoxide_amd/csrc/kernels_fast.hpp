@@ -168,6 +168,63 @@ __global__ void __launch_bounds__(WG) k_scalarmul_var_fast(size_t n, const uint8
   }
 }
 
+// Fixed-base comb on Jacobian coordinates: same table and digit order as
+// mul_base_table (src/curve/projective.rs:965-981) -- window w <-> byte n[len-1-w/2], even w =
+// low nibble -- but each of the NW additions is a mixed addition with the affine table entry
+// (11 mul instead of 14), with the same special-case patching as the variable-base kernel.
+// Writes un-normalised Jacobian rows for k_batch_to_affine.
+template <class C>
+__global__ void __launch_bounds__(WG) k_scalarmul_base_fast(size_t n, const uint8_t* __restrict__ scalars,
+                                                            const uint32_t* __restrict__ table,
+                                                            uint32_t* __restrict__ jac_out, uint8_t* __restrict__ flags) {
+  constexpr int L = C::L;
+  constexpr int SB = C::SB;
+  constexpr int NW = 2 * SB;
+  constexpr int W3 = row_words<L>();
+  for (size_t base = (size_t)blockIdx.x * WG; base < n; base += (size_t)gridDim.x * WG) {
+    const size_t gid = base + threadIdx.x;
+    const bool active = gid < n;
+    const size_t idx = active ? gid : n - 1;
+    const uint8_t* __restrict__ k = scalars + idx * (size_t)SB;
+    Jac<C> q;
+    fe_set<C>(q.x, C::ONE);
+    fe_set<C>(q.y, C::ONE);
+    fe_zero<C>(q.z);  // infinity
+    for (int w = 0; w < NW; ++w) {
+      uint32_t byte = k[SB - 1 - (w >> 1)];
+      uint32_t d = (w & 1) ? (byte >> 4) : (byte & 0x0f);
+      const uint32_t* __restrict__ e = table + ((size_t)w * 16 + (d ? d : 1)) * (2 * L);
+      Fe<L> x2, y2;
+#pragma unroll
+      for (int i = 0; i < L; ++i) { x2.v[i] = e[i]; y2.v[i] = e[L + i]; }
+      const bool q_inf = fe_is_zero<C>(q.z);
+      const bool e_skip = (d == 0);
+      Jac<C> sum;
+      bool hz, rz;
+      jac_madd_raw<C>(sum, hz, rz, q, x2, y2);
+      const bool same_x = hz && !q_inf && !e_skip;
+      const bool need_dbl = same_x && rz;
+      if (same_x && !rz) fe_zero<C>(sum.z);  // q == -entry
+      Jac<C> ej;
+      ej.x = x2; ej.y = y2;
+      fe_set<C>(ej.z, C::ONE);
+      jac_select<C>(sum, q_inf, ej, sum);
+      if (__builtin_amdgcn_ballot_w64(need_dbl) != 0) {  // q == entry: rare, wave-uniform branch
+        Jac<C> t;
+        jac_dbl<C>(t, q);
+        jac_select<C>(sum, need_dbl, t, sum);
+      }
+      jac_select<C>(q, e_skip, q, sum);
+    }
+    if (active) {
+      Pt<C> res;
+      res.x = q.x; res.y = q.y; res.z = q.z;
+      row_store<C>(jac_out + idx * (size_t)W3, res);
+      flags[idx] = 0;
+    }
+  }
+}
+
 // Normalise a batch of un-normalised points (rows of W3 words: X, Y, Z Montgomery limbs).
 //   MODE 0: homogeneous x = X/Z, y = Y/Z, big-endian bytes (projective.rs:655-682)
 //   MODE 1: Jacobian x = X/Z^2, y = Y/Z^3, big-endian bytes

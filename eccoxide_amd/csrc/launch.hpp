@@ -29,6 +29,9 @@ struct CurveOps {
   hipError_t (*var_fast)(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint8_t* points,
                          uint32_t* jac, uint8_t* flags, uint32_t* scratch, uint32_t opts);
   hipError_t (*to_affine_jac)(int grid, hipStream_t s, size_t n, const uint32_t* jac, uint8_t* out, uint8_t* flags);
+  // fast fixed-base comb (may be null): Jacobian mixed additions into `jac`
+  hipError_t (*base_fast)(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint32_t* table,
+                          uint32_t* jac, uint8_t* flags);
   // batched normalisation of homogeneous rows (mirror / comb kernels run with OPT_OUT_ROWS)
   hipError_t (*to_affine_hom)(int grid, hipStream_t s, size_t n, const uint32_t* rows, uint8_t* out, uint8_t* flags);
 };

@@ -103,8 +103,9 @@ class Engine:
         res = (out.raw[: n * 2 * fb], flags.raw[:n])
         return res + (proj.raw[: n * _proj_width(cid)],) if want_proj else res
 
-    def scalarmul_base(self, curve, scalars: bytes, *, want_proj: bool = False):
-        """out[i] = scalars[i] * G via the fixed-base comb table."""
+    def scalarmul_base(self, curve, scalars: bytes, *, want_proj: bool = False, mirror: bool = False):
+        """out[i] = scalars[i] * G via the fixed-base comb table.
+        mirror=True (implied by want_proj) runs the reference-mirroring kernels."""
         cid = curve_id(curve)
         sb, fb = scalar_bytes(cid), field_bytes(cid)
         if len(scalars) % sb:
@@ -113,7 +114,8 @@ class Engine:
         out = ctypes.create_string_buffer(max(1, n * 2 * fb))
         flags = ctypes.create_string_buffer(max(1, n))
         proj = ctypes.create_string_buffer(max(1, n * _proj_width(cid))) if want_proj else None
-        rc = self._lib.eccx_scalarmul_base(self._ctx, cid, n, scalars, out, flags, proj, 0)
+        rc = self._lib.eccx_scalarmul_base(self._ctx, cid, n, scalars, out, flags, proj,
+                                           MIRROR_REFERENCE if mirror else 0)
         self._check(rc)
         res = (out.raw[: n * 2 * fb], flags.raw[:n])
         return res + (proj.raw[: n * _proj_width(cid)],) if want_proj else res

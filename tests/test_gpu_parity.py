@@ -60,8 +60,12 @@ def test_var_matches_oracle(engine, oracle, curve, n):
 def test_base_matches_oracle(engine, oracle, curve, n):
     ks = W.random_scalars(curve, n, seed=300 + n).tobytes()
     want_out, want_inf, want_proj = oracle.base(curve, ks, threads=16)
-    out, flags, proj = engine.scalarmul_base(curve, ks, want_proj=True)
+    out, flags, proj = engine.scalarmul_base(curve, ks, want_proj=True)   # reference-mirroring kernels
     assert out == want_out and flags == want_inf and proj == want_proj
+    out, flags = engine.scalarmul_base(curve, ks)                         # default (fast) kernels
+    assert out == want_out and flags == want_inf
+    out, flags = engine.scalarmul_base(curve, ks, mirror=True)            # mirror + batched normalisation
+    assert out == want_out and flags == want_inf
 
 
 def test_empty_batch(engine):
@@ -96,6 +100,8 @@ def test_edge_scalars(engine, oracle, curve):
     want = oracle.base(curve, ks)
     got = engine.scalarmul_base(curve, ks, want_proj=True)
     assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2]
+    fast = engine.scalarmul_base(curve, ks)
+    assert fast[0] == want[0] and fast[1] == want[1]
     # 1 * G == G
     assert got[0][2 * fb: 4 * fb] == g
 
@@ -126,6 +132,14 @@ def test_fast_ladder_exceptional_cases(engine, oracle, curve):
     got = engine.scalarmul_var(curve, ks, pts)
     assert got[0] == want[0] and got[1] == want[1]
     got = engine.scalarmul_var(curve, ks, pts, mirror=True)
+    assert got[0] == want[0] and got[1] == want[1]
+    # fixed-base comb (Jacobian mixed additions): k = n hits P + (-P) at the top window;
+    # k = 2^256 - n (BLS) / 2^522 - n (P-521) makes the running sum equal the top window's
+    # entry, i.e. the P + P case of the comb
+    extra = {"bls12_381_g1": [(1 << 256) - order], "p521r1": [(1 << 522) - order]}.get(curve, [])
+    ks = b"".join(v.to_bytes(sb, "big") for v in vals + extra)
+    want = oracle.base(curve, ks)
+    got = engine.scalarmul_base(curve, ks)
     assert got[0] == want[0] and got[1] == want[1]
 
 
