@@ -58,6 +58,9 @@ def main():
     ap.add_argument("--workload", default="p256r1_var_2^20", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1 << 16)
+    ap.add_argument("--variant", default="default", choices=["default", "mirror", "lds", "l2"],
+                    help="default: fast kernels; mirror: reference-mirroring kernels; "
+                         "lds / l2: ed25519 fixed base with the comb table forced into LDS / read through L2")
     args = ap.parse_args()
 
     import torch
@@ -95,11 +98,14 @@ def main():
     stream = torch.cuda.current_stream(dev)
     sizes = [n] * world
 
+    mirror = args.variant == "mirror"
+
     def step():
         if op == "var":
-            eng.scalarmul_var_t(curve, ks, pts, out, flags, stream=stream.cuda_stream)
+            eng.scalarmul_var_t(curve, ks, pts, out, flags, stream=stream.cuda_stream, mirror=mirror)
         else:
-            eng.scalarmul_base_t(curve, ks, out, flags, stream=stream.cuda_stream)
+            eng.scalarmul_base_t(curve, ks, out, flags, stream=stream.cuda_stream, mirror=mirror,
+                                 table_in_lds={"lds": True, "l2": False}.get(args.variant))
 
     def gather():
         if world > 1:

@@ -14,13 +14,25 @@ hipError_t base_(int grid, hipStream_t s, size_t n, const uint8_t* scalars, cons
   hipLaunchKernelGGL(k_ed_scalarmul_base<ED25519>, dim3(grid), dim3(WG), 0, s, n, scalars, table, out, flags, proj, opts);
   return hipGetLastError();
 }
+hipError_t base_lds_(int cus, hipStream_t s, size_t n, const uint8_t* scalars, const uint32_t* table, uint32_t* rows,
+                     uint8_t* flags) {
+  constexpr size_t lds_bytes = (size_t)64 * 16 * 3 * ED25519::L * sizeof(uint32_t);  // 96 KiB
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ed_scalarmul_base_lds<ED25519>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (attr != hipSuccess) return attr;
+  size_t need = (n + ED_LDS_BLOCK - 1) / ED_LDS_BLOCK;
+  int grid = (int)(need < (size_t)cus ? (need ? need : 1) : (size_t)cus);  // one workgroup per CU
+  hipLaunchKernelGGL(k_ed_scalarmul_base_lds<ED25519>, dim3(grid), dim3(ED_LDS_BLOCK), lds_bytes, s, n, scalars, table,
+                     rows, flags);
+  return hipGetLastError();
+}
 hipError_t to_affine_hom_(int grid, hipStream_t s, size_t n, const uint32_t* rows, uint8_t* out, uint8_t* flags) {
   hipLaunchKernelGGL((k_batch_to_affine<ED25519, NORM_EDWARDS, TO_AFFINE_U>), dim3(grid), dim3(WG), 0, s, n, rows, out, flags);
   return hipGetLastError();
 }
 }  // namespace
 const CurveOps& ops_ED25519() {
-  static const CurveOps o = {{ED25519::FB, ED25519::SB, ED25519::L, 4 * ED25519::L, 0, 1, 0, row_words<ED25519::L>()}, var_, base_, nullptr, nullptr, nullptr, to_affine_hom_};
+  static const CurveOps o = {{ED25519::FB, ED25519::SB, ED25519::L, 4 * ED25519::L, 0, 1, 0, row_words<ED25519::L>()}, var_, base_, nullptr, nullptr, nullptr, base_lds_, to_affine_hom_};
   return o;
 }
 }  // namespace eccx

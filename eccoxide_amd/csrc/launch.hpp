@@ -32,6 +32,9 @@ struct CurveOps {
   // fast fixed-base comb (may be null): Jacobian mixed additions into `jac`
   hipError_t (*base_fast)(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint32_t* table,
                           uint32_t* jac, uint8_t* flags);
+  // fixed-base variant with the comb table staged in LDS (may be null); picks its own grid
+  hipError_t (*base_lds)(int cus, hipStream_t s, size_t n, const uint8_t* scalars, const uint32_t* table,
+                         uint32_t* rows, uint8_t* flags);
   // batched normalisation of homogeneous rows (mirror / comb kernels run with OPT_OUT_ROWS)
   hipError_t (*to_affine_hom)(int grid, hipStream_t s, size_t n, const uint32_t* rows, uint8_t* out, uint8_t* flags);
 };

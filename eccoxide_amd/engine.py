@@ -15,6 +15,8 @@ CURVE_NAMES = {v: k for k, v in CURVE_IDS.items()}
 
 VALIDATE_POINTS = 1 << 0
 MIRROR_REFERENCE = 1 << 1
+TABLE_IN_LDS = 1 << 2
+TABLE_IN_L2 = 1 << 3
 FLAG_FINITE, FLAG_INFINITY, FLAG_REJECTED = 0, 1, 2
 
 
@@ -155,7 +157,8 @@ class Engine:
         self._check(rc)
         return out, flags
 
-    def scalarmul_base_t(self, curve, scalars, out=None, flags=None, proj=None, *, stream: Optional[int] = None):
+    def scalarmul_base_t(self, curve, scalars, out=None, flags=None, proj=None, *, stream: Optional[int] = None,
+                         table_in_lds: Optional[bool] = None, mirror: bool = False):
         import torch
 
         cid = curve_id(curve)
@@ -172,6 +175,8 @@ class Engine:
             stream = torch.cuda.current_stream(scalars.device).cuda_stream
         rc = self._lib.eccx_scalarmul_base_dev(self._ctx, cid, n, scalars.data_ptr(), out.data_ptr(),
                                                flags.data_ptr(), proj.data_ptr() if proj is not None else None,
-                                               0, stream)
+                                               (0 if table_in_lds is None else (TABLE_IN_LDS if table_in_lds else TABLE_IN_L2))
+                                               | (MIRROR_REFERENCE if mirror else 0),
+                                               stream)
         self._check(rc)
         return out, flags

@@ -76,6 +76,12 @@ enum {
                                      1.5x faster.  Off-curve inputs (only reachable without
                                      ECCX_VALIDATE_POINTS) give unspecified output by default and
                                      the reference's arithmetic under this option. */
+  ,
+  ECCX_TABLE_IN_LDS = 1u << 2,   /* fixed base, edwards25519 only: stage the whole comb table
+                                     (96 KiB) in LDS, one 1024-thread workgroup per CU, instead
+                                     of reading it through L1/L2.  Default for batches >= 2^16.
+                                     Same results; see DESIGN.md for the measured difference. */
+  ECCX_TABLE_IN_L2 = 1u << 3     /* never stage the comb table in LDS */
 };
 
 /* flag values written per unit */
