@@ -44,6 +44,19 @@ WORKLOADS = {
     "p521r1_var_2^19": ("p521r1", "var", 1 << 19, 330, _var_muls(132, 8, 780), 2 * 17 * 17),
     "bls12_381_g1_var_2^20": ("bls12_381_g1", "var", 1 << 20, 224, _var_muls(64, 7, 570), 2 * 12 * 12),
 }
+# HBM bytes per launch measured with rocprofv3 PMC passes (tools/profile.sh; summaries under
+# profiles/): FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for 16-byte-per-lane
+# reads on gfx950, plus WRITE_SIZE, summed over the kernels of one step.  Counters cannot be
+# read from inside this process, so the figure is the committed measurement of this very
+# workload, not a live one; null where no profile has been taken.
+MEASURED_TRAFFIC = {
+    "p256r1_var_2^20": {"bytes": 2 * (8623171755 + 113180041) + 2618476944 + 105923264,
+                        "fetch_raw": 8623171755 + 113180041, "write": 2618476944 + 105923264,
+                        "source": "profiles/r01_p256r1_var_fast.json"},
+    "ed25519_base_2^20": {"bytes": 2 * (23648203 + 112667744) + 117058688 + 105948448,
+                          "fetch_raw": 23648203 + 112667744, "write": 117058688 + 105948448,
+                          "source": "profiles/r01_ed25519_base.json"},
+}
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # v_mad_u64_u32 issue peak measured by tools/ubench/valu_rates.hip on MI355X
 # (profiles/r01_valu_rates.jsonl): 33.0e12 lane-MACs/s with 8 waves per SIMD.
@@ -192,9 +205,14 @@ def main():
                        "global_batch": n * world, "parallelism": f"shard{world}" if world > 1 else "single",
                        "gather": "rccl gather to rank 0 inside the step" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "frac": ach / HBM_PEAK_GBS,
+                         "traffic": (MEASURED_TRAFFIC[args.workload]["bytes"]
+                                     if args.workload in MEASURED_TRAFFIC and args.variant == "default" else None),
+                         "traffic_detail": MEASURED_TRAFFIC.get(args.workload) if args.variant == "default" else None,
                          "kernel_ms": kernel_ms, "alg_bytes_per_unit": alg_bytes,
-                         "note": "integer-VALU bound path; see valu"},
+                         "alg_bytes_per_launch": alg_bytes * n,
+                         "note": "integer-VALU bound path, see valu; traffic above the algorithmic bytes is "
+                                 "the per-lane window table of the variable-base ladder (DESIGN.md §6)"},
             "valu": {"bound": "v_mad_u64_u32 issue", "achieved": mac_rate / 1e12, "peak": MAC_PEAK_PER_S / 1e12,
                      "unit": "T MAC32/s", "frac": mac_rate / MAC_PEAK_PER_S,
                      "macs_per_unit": field_muls * macs_per_mul},
