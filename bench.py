@@ -40,6 +40,7 @@ WORKLOADS = {
     "p256r1_var_2^20": ("p256r1", "var", 1 << 20, 160, _var_muls(64, 8, 383), 8 * 8 + 8 * 5),
     "ed25519_base_2^20": ("ed25519", "base", 1 << 20, 96, 64 * 7 + 2 + (380 + 7) // 8 + 7, 8 * 8 + 8),
     "p256r1_base_2^20": ("p256r1", "base", 1 << 20, 96, 64 * 11 + (383 + 7) // 8 + 9, 8 * 8 + 8 * 5),
+    "x25519_2^20": ("ed25519", "x25519", 1 << 20, 96, 256 * 9 + (380 + 7) // 8 + 6, 8 * 8 + 8),
     "p384r1_var_2^19": ("p384r1", "var", 1 << 19, 240, _var_muls(96, 8, 575), 12 * 12 + 12 * 10),
     "p521r1_var_2^19": ("p521r1", "var", 1 << 19, 330, _var_muls(132, 8, 780), 2 * 17 * 17),
     "bls12_381_g1_var_2^20": ("bls12_381_g1", "var", 1 << 20, 224, _var_muls(64, 7, 570), 2 * 12 * 12),
@@ -103,10 +104,14 @@ def main():
         rs = torch.from_numpy(W.random_scalars(curve, n, seed=1000 + rank)).to(dev)
         pts, _ = eng.scalarmul_base_t(curve, rs)  # r_i * G: bases in the prime-order subgroup
         del rs
+    elif op == "x25519":
+        rs = torch.from_numpy(W.random_scalars(curve, n, seed=1000 + rank)).to(dev)
+        pts, _ = eng.x25519_t(rs)  # peer public keys X25519(r_i, 9)
+        del rs
     else:
         eng.scalarmul_base_t(curve, ks[:256].contiguous())  # builds the comb table
         pts = None
-    out = torch.empty((n, 2 * fb), dtype=torch.uint8, device=dev)
+    out = torch.empty((n, 32 if op == "x25519" else 2 * fb), dtype=torch.uint8, device=dev)
     flags = torch.empty((n,), dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev)
     sizes = [n] * world
@@ -116,6 +121,8 @@ def main():
     def step():
         if op == "var":
             eng.scalarmul_var_t(curve, ks, pts, out, flags, stream=stream.cuda_stream, mirror=mirror)
+        elif op == "x25519":
+            eng.x25519_t(ks, pts, out, flags, stream=stream.cuda_stream)
         else:
             eng.scalarmul_base_t(curve, ks, out, flags, stream=stream.cuda_stream, mirror=mirror,
                                  table_in_lds={"lds": True, "l2": False}.get(args.variant))
@@ -164,6 +171,8 @@ def main():
         s_k = ks[idx].cpu().numpy().tobytes()
         if op == "var":
             w_out, w_inf, _ = ora.var(curve, s_k, pts[idx].cpu().numpy().tobytes(), threads=8)
+        elif op == "x25519":
+            w_out, w_inf = ora.x25519(s_k, pts[idx].cpu().numpy().tobytes(), threads=8)
         else:
             w_out, w_inf, _ = ora.base(curve, s_k, threads=8)
         parity = (out[idx].cpu().numpy().tobytes() == w_out) and (flags[idx].cpu().numpy().tobytes() == w_inf)
@@ -171,10 +180,12 @@ def main():
             cores = min(16, os.cpu_count() or 1)
             m = min(n, args.cpu_sample)
             c_k = ks[:m].cpu().numpy().tobytes()
-            c_p = pts[:m].cpu().numpy().tobytes() if op == "var" else None
+            c_p = pts[:m].cpu().numpy().tobytes() if op in ("var", "x25519") else None
             t1 = time.perf_counter()
             if op == "var":
                 ora.var(curve, c_k, c_p, threads=cores)
+            elif op == "x25519":
+                ora.x25519(c_k, c_p, threads=cores)
             else:
                 ora.base(curve, c_k, threads=cores)
             dt = time.perf_counter() - t1
@@ -189,7 +200,8 @@ def main():
         mac_rate = field_muls * macs_per_mul * n / (kernel_ms * 1e-3)
         line = {
             "metric": "variable-base scalarmuls/sec (batch) per GPU + achieved HBM GB/s vs roofline"
-            if op == "var" else "fixed-base scalarmuls/sec (batch) per GPU + achieved HBM GB/s vs roofline",
+            if op == "var" else ("X25519 scalarmuls/sec (batch) per GPU + achieved HBM GB/s vs roofline" if op == "x25519"
+                                 else "fixed-base scalarmuls/sec (batch) per GPU + achieved HBM GB/s vs roofline"),
             "value": value,
             "unit": "scalarmuls/s",
             "n_gpus": world,

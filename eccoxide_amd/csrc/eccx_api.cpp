@@ -381,6 +381,61 @@ int eccx_scalarmul_base(eccx_ctx* ctx, int curve, size_t n, const uint8_t* scala
   return run_host(ctx, curve, true, n, scalars, nullptr, out, flags, proj, opts);
 }
 
+int eccx_x25519_dev(eccx_ctx* ctx, size_t n, const void* d_scalars, const void* d_u, void* d_out, void* d_flags,
+                    uint32_t opts, void* stream) {
+  if (!ctx) return ECCX_ERR_ARG;
+  if (n == 0) return ECCX_OK;
+  if (!d_scalars || !d_out || !d_flags) return ECCX_ERR_ARG;
+  const CurveOps* ops = ops_of(ECCX_ED25519);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc = ensure_rows(ctx, ops, n);
+  if (rc) return rc;
+  size_t need = (n + eccx::LAUNCH_WG - 1) / eccx::LAUNCH_WG;
+  int grid = (int)std::max<size_t>(1, std::min(need, (size_t)ctx->cus * 8));
+  const uint32_t kopts = (opts & ECCX_X25519_RAW_LADDER) ? 0u : (1u << 4);  // OPT_X25519_RFC
+  HIP_TRY(ctx, eccx::launch_x25519_ladder(grid, s, n, static_cast<const uint8_t*>(d_scalars),
+                                          static_cast<const uint8_t*>(d_u), ctx->jac, static_cast<uint8_t*>(d_flags),
+                                          kopts));
+  HIP_TRY(ctx, eccx::launch_x25519_to_u(norm_grid(ctx, n), s, n, ctx->jac, static_cast<uint8_t*>(d_out),
+                                        static_cast<uint8_t*>(d_flags)));
+  return ECCX_OK;
+}
+
+int eccx_x25519(eccx_ctx* ctx, size_t n, const uint8_t* scalars, const uint8_t* u, uint8_t* out, uint8_t* flags,
+                uint32_t opts) {
+  if (!ctx) return ECCX_ERR_ARG;
+  if (n == 0) return ECCX_OK;
+  if (!scalars || !out || !flags) return ECCX_ERR_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  uint8_t *d_k = nullptr, *d_u = nullptr, *d_o = nullptr, *d_f = nullptr;
+  auto cleanup = [&]() {
+    if (d_k) (void)hipFree(d_k);
+    if (d_u) (void)hipFree(d_u);
+    if (d_o) (void)hipFree(d_o);
+    if (d_f) (void)hipFree(d_f);
+  };
+  auto fail = [&](hipError_t e, const char* what) {
+    ctx->err = std::string(what) + ": " + hipGetErrorString(e);
+    cleanup();
+    return e == hipErrorOutOfMemory ? ECCX_ERR_NOMEM : ECCX_ERR_HIP;
+  };
+  hipError_t e;
+  if ((e = hipMalloc(&d_k, n * 32)) != hipSuccess) return fail(e, "hipMalloc");
+  if ((e = hipMalloc(&d_o, n * 32)) != hipSuccess) return fail(e, "hipMalloc");
+  if ((e = hipMalloc(&d_f, n)) != hipSuccess) return fail(e, "hipMalloc");
+  if (u && (e = hipMalloc(&d_u, n * 32)) != hipSuccess) return fail(e, "hipMalloc");
+  if ((e = hipMemcpyAsync(d_k, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail(e, "hipMemcpyAsync");
+  if (u && (e = hipMemcpyAsync(d_u, u, n * 32, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail(e, "hipMemcpyAsync");
+  int rc = eccx_x25519_dev(ctx, n, d_k, d_u, d_o, d_f, opts, ctx->stream);
+  if (rc) { cleanup(); return rc; }
+  if ((e = hipMemcpyAsync(out, d_o, n * 32, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) return fail(e, "hipMemcpyAsync");
+  if ((e = hipMemcpyAsync(flags, d_f, n, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) return fail(e, "hipMemcpyAsync");
+  if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(e, "hipStreamSynchronize");
+  cleanup();
+  return ECCX_OK;
+}
+
 int eccx_comb_table(eccx_ctx* ctx, int curve, uint8_t* out) {
   const CurveOps* ops = ops_of(curve);
   if (!ctx || !out) return ECCX_ERR_ARG;

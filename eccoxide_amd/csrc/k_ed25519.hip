@@ -31,6 +31,16 @@ hipError_t to_affine_hom_(int grid, hipStream_t s, size_t n, const uint32_t* row
   return hipGetLastError();
 }
 }  // namespace
+hipError_t launch_x25519_ladder(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint8_t* u, uint32_t* rows,
+                                uint8_t* flags, uint32_t opts) {
+  hipLaunchKernelGGL(k_x25519_ladder<ED25519>, dim3(grid), dim3(WG), 0, s, n, scalars, u, rows, flags, opts);
+  return hipGetLastError();
+}
+hipError_t launch_x25519_to_u(int grid, hipStream_t s, size_t n, const uint32_t* rows, uint8_t* out, uint8_t* flags) {
+  hipLaunchKernelGGL((k_batch_to_affine<ED25519, NORM_MONTGOMERY_U, TO_AFFINE_U>), dim3(grid), dim3(WG), 0, s, n, rows, out,
+                     flags);
+  return hipGetLastError();
+}
 const CurveOps& ops_ED25519() {
   static const CurveOps o = {{ED25519::FB, ED25519::SB, ED25519::L, 4 * ED25519::L, 0, 1, 0, row_words<ED25519::L>()}, var_, base_, nullptr, nullptr, nullptr, base_lds_, to_affine_hom_};
   return o;

@@ -287,7 +287,9 @@ __global__ void __launch_bounds__(ED_LDS_BLOCK) k_ed_scalarmul_base_lds(size_t n
 //           (curve25519.rs:663-666; Z is never 0 on a complete Edwards curve)
 // flags[i] on entry: 2 marks a rejected input (kept, zero output); on exit 1 marks infinity.
 // Thread t of a workgroup handles units tile + u*WG + t, u = 0..U-1, with one inversion.
-enum { NORM_HOMOGENEOUS = 0, NORM_JACOBIAN = 1, NORM_EDWARDS = 2 };
+//   MODE 3: curve25519 x-only: u = X/Z with 0 for Z = 0, 32 little-endian bytes per unit,
+//           flag 1 = result is zero (curve25519.rs:529-532; x25519.rs:33-35)
+enum { NORM_HOMOGENEOUS = 0, NORM_JACOBIAN = 1, NORM_EDWARDS = 2, NORM_MONTGOMERY_U = 3 };
 template <class C, int MODE, int U>
 __global__ void __launch_bounds__(WG) k_batch_to_affine(size_t n, const uint32_t* __restrict__ pts,
                                                         uint8_t* __restrict__ out, uint8_t* __restrict__ flags) {
@@ -347,7 +349,13 @@ __global__ void __launch_bounds__(WG) k_batch_to_affine(size_t n, const uint32_t
       if (i < n) {
         const bool rejected = flags[i] == 2;
         Fe<L> t;
-        if constexpr (MODE == NORM_EDWARDS) {
+        if constexpr (MODE == NORM_MONTGOMERY_U) {
+          // u = X * invert_or_zero(Z) (curve25519.rs:529-532): Z = 0 gives u = 0
+          fe_from_mont<C>(t, ax);
+          if (!present) fe_zero<C>(t);
+          fe_store_le<C>(out + i * (size_t)FB, t);
+          flags[i] = fe_is_zero<C>(t) ? 1 : 0;
+        } else if constexpr (MODE == NORM_EDWARDS) {
           const bool neutral = fe_is_zero<C>(ax) && fe_eq<C>(ay, one);
           fe_from_mont<C>(t, ax);
           if (rejected) fe_zero<C>(t);

@@ -46,6 +46,11 @@ const CurveOps& ops_P521();
 const CurveOps& ops_BLS12_381();
 const CurveOps& ops_ED25519();
 
+// curve25519 x-only ladder (k_ed25519.hip): rows of row_words<8>() = 24 words per unit
+hipError_t launch_x25519_ladder(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint8_t* u,
+                                uint32_t* rows, uint8_t* flags, uint32_t opts);
+hipError_t launch_x25519_to_u(int grid, hipStream_t s, size_t n, const uint32_t* rows, uint8_t* out, uint8_t* flags);
+
 constexpr int LAUNCH_WG = 256;
 
 }  // namespace eccx

@@ -17,6 +17,7 @@ VALIDATE_POINTS = 1 << 0
 MIRROR_REFERENCE = 1 << 1
 TABLE_IN_LDS = 1 << 2
 TABLE_IN_L2 = 1 << 3
+X25519_RAW_LADDER = 1 << 4
 FLAG_FINITE, FLAG_INFINITY, FLAG_REJECTED = 0, 1, 2
 
 
@@ -121,6 +122,40 @@ class Engine:
         self._check(rc)
         res = (out.raw[: n * 2 * fb], flags.raw[:n])
         return res + (proj.raw[: n * _proj_width(cid)],) if want_proj else res
+
+    def x25519(self, scalars: bytes, u: Optional[bytes] = None, *, raw_ladder: bool = False):
+        """X25519 over a batch: returns (n x 32 little-endian u-coordinates, flags).
+        Default: RFC 7748 semantics (protocol::x25519::x25519): little-endian scalars, clamped;
+        raw_ladder=True: MontgomeryPoint::scale_bytes, big-endian scalars used as given.
+        u=None multiplies the base point u = 9."""
+        if len(scalars) % 32 or (u is not None and len(u) != len(scalars)):
+            raise ValueError("scalars / u must be n x 32 bytes")
+        n = len(scalars) // 32
+        out = ctypes.create_string_buffer(max(1, n * 32))
+        flags = ctypes.create_string_buffer(max(1, n))
+        rc = self._lib.eccx_x25519(self._ctx, n, scalars, u, out, flags, X25519_RAW_LADDER if raw_ladder else 0)
+        self._check(rc)
+        return out.raw[: n * 32], flags.raw[:n]
+
+    def x25519_t(self, scalars, u=None, out=None, flags=None, *, raw_ladder: bool = False,
+                 stream: Optional[int] = None):
+        """Device-tensor form of x25519 (torch.uint8 CUDA tensors, n x 32)."""
+        import torch
+
+        n = scalars.numel() // 32
+        if out is None:
+            out = torch.empty((n, 32), dtype=torch.uint8, device=scalars.device)
+        if flags is None:
+            flags = torch.empty((n,), dtype=torch.uint8, device=scalars.device)
+        for t in (scalars, out, flags) + ((u,) if u is not None else ()):
+            if not (t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()):
+                raise ValueError("tensors must be contiguous torch.uint8 CUDA tensors")
+        if stream is None:
+            stream = torch.cuda.current_stream(scalars.device).cuda_stream
+        rc = self._lib.eccx_x25519_dev(self._ctx, n, scalars.data_ptr(), u.data_ptr() if u is not None else None,
+                                       out.data_ptr(), flags.data_ptr(), X25519_RAW_LADDER if raw_ladder else 0, stream)
+        self._check(rc)
+        return out, flags
 
     def comb_table(self, curve) -> bytes:
         """The fixed-base table in the reference's on-disk layout (NW x 15 x (x||y))."""

@@ -81,7 +81,8 @@ enum {
                                      (96 KiB) in LDS, one 1024-thread workgroup per CU, instead
                                      of reading it through L1/L2.  Default for batches >= 2^16.
                                      Same results; see DESIGN.md for the measured difference. */
-  ECCX_TABLE_IN_L2 = 1u << 3     /* never stage the comb table in LDS */
+  ECCX_TABLE_IN_L2 = 1u << 3,    /* never stage the comb table in LDS */
+  ECCX_X25519_RAW_LADDER = 1u << 4 /* eccx_x25519: raw MontgomeryPoint::scale_bytes semantics */
 };
 
 /* flag values written per unit */
@@ -120,6 +121,23 @@ int eccx_scalarmul_var_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_sca
                            void* d_out, void* d_flags, void* d_proj, uint32_t opts, void* stream);
 int eccx_scalarmul_base_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_scalars, void* d_out,
                             void* d_flags, void* d_proj, uint32_t opts, void* stream);
+
+/* X25519: the curve25519 x-only Montgomery ladder.
+ *   default            protocol::x25519::x25519 (src/protocol/x25519.rs:36-45): `scalars` are
+ *                      n x 32 little-endian RFC 7748 scalars, clamped on use (x25519.rs:15-20);
+ *                      the top bit of each u-coordinate is masked (decode_u, :24-29).
+ *   ECCX_X25519_RAW_LADDER  MontgomeryPoint::scale_bytes (src/curve/curve25519.rs:535-541 ->
+ *                      ladder :474-513): `scalars` are the n x 32 BIG-endian strings the ladder
+ *                      consumes, no clamping; u is reduced mod p as given.
+ *   u    : n x 32 little-endian u-coordinates, or NULL for the base point u = 9
+ *          (x25519_base, x25519.rs:49-51)
+ *   out  : n x 32 little-endian u-coordinates of the results
+ *   flags: 1 where the result is zero (point at infinity / low-order input: callers doing
+ *          Diffie-Hellman must reject it, x25519.rs:33-35), else 0 */
+int eccx_x25519(eccx_ctx* ctx, size_t n, const uint8_t* scalars, const uint8_t* u, uint8_t* out, uint8_t* flags,
+                uint32_t opts);
+int eccx_x25519_dev(eccx_ctx* ctx, size_t n, const void* d_scalars, const void* d_u, void* d_out, void* d_flags,
+                    uint32_t opts, void* stream);
 
 /* The fixed-base comb table in the reference's on-disk layout (src/params/comb/<curve>.rs):
  * NW x 15 entries (j+1)*16^i*G as x||y, FB bytes each, big-endian (little-endian for

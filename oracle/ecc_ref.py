@@ -438,6 +438,57 @@ def ed25519_secret_scalar(seed: bytes) -> int:
     return int.from_bytes(bytes(h), "little") % ED25519.n
 
 
+# ---- Montgomery x-only ladder (src/curve/curve25519.rs:472-513) ----------------
+X25519_A24 = 121666  # MONT_A24_BYTES, curve25519.rs:374-377
+
+
+def ref_ladder(base_u: int, k_be: bytes) -> int:
+    """curve25519.rs:474-513: returns the u-coordinate of k*P (0 for the point at infinity)."""
+    p = _P25519
+    x1 = base_u % p
+    x2, z2, x3, z3 = 1, 0, x1, 1
+    swap = 0
+    for byte in k_be:
+        for i in range(7, -1, -1):
+            bit = (byte >> i) & 1
+            swap ^= bit
+            if swap:
+                x2, x3 = x3, x2
+                z2, z3 = z3, z2
+            swap = bit
+            a = (x2 + z2) % p; aa = a * a % p
+            b = (x2 - z2) % p; bb = b * b % p
+            e = (aa - bb) % p
+            c = (x3 + z3) % p; d = (x3 - z3) % p
+            da = d * a % p; cb = c * b % p
+            x3 = (da + cb) ** 2 % p
+            z3 = x1 * ((da - cb) ** 2 % p) % p
+            x2 = aa * bb % p
+            z2 = e * ((bb + X25519_A24 * e) % p) % p
+    if swap:
+        x2, x3 = x3, x2
+        z2, z3 = z3, z2
+    return x2 * pow(z2, p - 2, p) % p  # invert_or_zero: 0 -> 0
+
+
+def ref_x25519(scalar_le: bytes, u_le: bytes) -> bytes:
+    """protocol/x25519.rs:14-45: clamp, reverse to big-endian, mask the top bit of u."""
+    k = bytearray(scalar_le)
+    k[0] &= 248
+    k[31] &= 127
+    k[31] |= 64
+    u = bytearray(u_le)
+    u[31] &= 0x7F
+    r = ref_ladder(int.from_bytes(bytes(u), "little"), bytes(reversed(k)))
+    return r.to_bytes(32, "little")
+
+
+def montgomery_u_of_edwards(y: int) -> int:
+    """u = (1 + y)/(1 - y) (curve25519.rs:790-798)"""
+    p = _P25519
+    return (1 + y) * pow(1 - y, -1, p) % p
+
+
 # --------------------------------------------------------------------------
 # Byte-level batch API (same conventions as the C ABI, include/eccx.h)
 # --------------------------------------------------------------------------

@@ -16,8 +16,8 @@
  *   affine     src/curve/projective.rs:655-682, curve25519.rs:663-666
  *
  * Parity pinning: tests/test_oracle_golden.py runs this library against every
- * golden vector the reference's tests hold for the path (tests/golden/*.json:
- * NIST kG, RFC 6979, RFC 8032, BLS G1 KATs, comb tables) and against the
+ * golden vector the reference's tests hold for the path (the JSON files under
+ * tests/golden: NIST kG, RFC 6979, RFC 8032, RFC 7748, BLS G1 KATs, comb tables) and against the
  * independent Python big-int oracle (oracle/ecc_ref.py).
  *
  * Build: make -C oracle   (gcc -O3 -march=native -shared -fPIC -pthread)
@@ -200,6 +200,45 @@ static void ed_mul_base(const ed_curve* C, ed_pt* r, const ed_pt* tab, const uin
   *r = q;
 }
 
+/* Montgomery x-only ladder, src/curve/curve25519.rs:474-513 (a24 = 121666, :374-377) */
+static void mont_ladder(const ed_curve* C, fe4_t* out_u, const fe4_t* base_u, const uint8_t* k_be, int len) {
+  const fe4_field* F = &C->F;
+  fe4_t a24, x1 = *base_u, x2, z2, x3 = *base_u, z3;
+  {
+    uint8_t buf[32] = {0};
+    buf[29] = 0x01; buf[30] = 0xdb; buf[31] = 0x42;
+    fe4_from_bytes_be(F, &a24, buf);
+  }
+  fe4_set_one(F, &x2); fe4_set_zero(&z2); fe4_set_one(F, &z3);
+  unsigned swap = 0;
+  for (int i = 0; i < len; i++)
+    for (int b = 7; b >= 0; b--) {
+      unsigned bit = (k_be[i] >> b) & 1;
+      swap ^= bit;
+      uint64_t mask = (uint64_t)0 - (uint64_t)swap;
+      for (int w = 0; w < 4; w++) {
+        uint64_t t = mask & (x2.v[w] ^ x3.v[w]); x2.v[w] ^= t; x3.v[w] ^= t;
+        t = mask & (z2.v[w] ^ z3.v[w]); z2.v[w] ^= t; z3.v[w] ^= t;
+      }
+      swap = bit;
+      fe4_t a, aa, bq, bb, e, c, d, da, cb, t;
+      fe4_add(F, &a, &x2, &z2); fe4_sqr(F, &aa, &a);
+      fe4_sub(F, &bq, &x2, &z2); fe4_sqr(F, &bb, &bq);
+      fe4_sub(F, &e, &aa, &bb);
+      fe4_add(F, &c, &x3, &z3); fe4_sub(F, &d, &x3, &z3);
+      fe4_mul(F, &da, &d, &a); fe4_mul(F, &cb, &c, &bq);
+      fe4_add(F, &t, &da, &cb); fe4_sqr(F, &x3, &t);
+      fe4_sub(F, &t, &da, &cb); fe4_sqr(F, &t, &t); fe4_mul(F, &z3, &x1, &t);
+      fe4_mul(F, &x2, &aa, &bb);
+      fe4_mul(F, &t, &a24, &e); fe4_add(F, &t, &bb, &t); fe4_mul(F, &z2, &e, &t);
+    }
+  if (swap) { fe4_t t = x2; x2 = x3; x3 = t; t = z2; z2 = z3; z3 = t; }
+  if (fe4_is_zero(&z2)) { fe4_set_zero(out_u); return; }  /* invert_or_zero */
+  fe4_t zi;
+  fe4_inv(F, &zi, &z2);
+  fe4_mul(F, out_u, &x2, &zi);
+}
+
 /* ---- global state ------------------------------------------------------- */
 static cw4_curve C256;
 static cw6_curve C384, CBLS;
@@ -366,6 +405,63 @@ int eccx_oracle_scalarmul_var(int curve, size_t n, const uint8_t* scalars, const
 int eccx_oracle_scalarmul_base(int curve, size_t n, const uint8_t* scalars, uint8_t* out, uint8_t* is_inf,
                                uint8_t* proj, int threads) {
   return run(curve, 1, n, scalars, NULL, out, is_inf, proj, threads);
+}
+
+/* X25519 / Montgomery ladder.
+ *   rfc = 1: protocol::x25519::x25519 (src/protocol/x25519.rs:36-45): scalars little-endian,
+ *            clamped; top bit of u masked.
+ *   rfc = 0: MontgomeryPoint::scale_bytes (src/curve/curve25519.rs:535-541): scalars are the
+ *            big-endian strings the ladder consumes, u reduced mod p as given.
+ * u == NULL uses the base point u = 9.  out: n x 32 little-endian u-coordinates;
+ * flags[i] = 1 when the result is 0 (point at infinity / low-order input). */
+typedef struct { size_t lo, hi; const uint8_t *k, *u; uint8_t *out, *flags; int rfc; } xjob;
+static void* run_xjob(void* arg) {
+  xjob* j = (xjob*)arg;
+  for (size_t i = j->lo; i < j->hi; i++) {
+    uint8_t k_be[32], ub[32];
+    if (j->rfc) {
+      uint8_t k[32];
+      memcpy(k, j->k + 32 * i, 32);
+      k[0] &= 248; k[31] &= 127; k[31] |= 64;
+      for (int b = 0; b < 32; b++) k_be[b] = k[31 - b];
+    } else {
+      memcpy(k_be, j->k + 32 * i, 32);
+    }
+    if (j->u) memcpy(ub, j->u + 32 * i, 32); else { memset(ub, 0, 32); ub[0] = 9; }
+    if (j->rfc) ub[31] &= 0x7f;
+    fe4_t u, r;
+    /* reduce the 256-bit little-endian value mod p: split off bit 255 (2^255 = 19 mod p) */
+    unsigned top = ub[31] >> 7;
+    ub[31] &= 0x7f;
+    fe4_from_bytes_le(&CED.F, &u, ub);
+    if (top) {
+      fe4_t c19; uint8_t b19[32] = {0}; b19[0] = 19;
+      fe4_from_bytes_le(&CED.F, &c19, b19);
+      fe4_add(&CED.F, &u, &u, &c19);
+    }
+    mont_ladder(&CED, &r, &u, k_be, 32);
+    fe4_to_bytes_le(&CED.F, j->out + 32 * i, &r);
+    j->flags[i] = (uint8_t)fe4_is_zero(&r);
+  }
+  return NULL;
+}
+int eccx_oracle_x25519(size_t n, const uint8_t* scalars, const uint8_t* u, uint8_t* out, uint8_t* flags, int rfc,
+                       int threads) {
+  if (!scalars || !out || !flags) return -2;
+  pthread_once(&once_curves, init_curves);
+  if (threads < 1) threads = 1;
+  if ((size_t)threads > n) threads = n ? (int)n : 1;
+  xjob* jobs = (xjob*)calloc((size_t)threads, sizeof(xjob));
+  pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
+  for (int t = 0; t < threads; t++) {
+    jobs[t] = (xjob){ n * (size_t)t / (size_t)threads, n * (size_t)(t + 1) / (size_t)threads, scalars, u, out, flags, rfc };
+    if (t > 0) pthread_create(&th[t], NULL, run_xjob, &jobs[t]);
+  }
+  run_xjob(&jobs[0]);
+  for (int t = 1; t < threads; t++) pthread_join(th[t], NULL);
+  free(jobs);
+  free(th);
+  return 0;
 }
 
 /* The comb table in the reference's on-disk order and encoding

@@ -62,6 +62,19 @@ class Oracle:
             assert rc == 0
         return out.raw[: n * 2 * self.fb(curve)], inf.raw[:n], proj.raw[: n * self._pw(curve)]
 
+    def x25519(self, scalars: bytes, u=None, rfc: bool = True, threads: int = 8):
+        """-> (n x 32 little-endian u-coordinates, flags)"""
+        n = len(scalars) // 32
+        out = ctypes.create_string_buffer(max(1, n * 32))
+        fl = ctypes.create_string_buffer(max(1, n))
+        f = self.lib.eccx_oracle_x25519
+        f.restype = ctypes.c_int
+        f.argtypes = [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                      ctypes.c_int, ctypes.c_int]
+        if n:
+            assert f(n, scalars, u, out, fl, 1 if rfc else 0, threads) == 0
+        return out.raw[: n * 32], fl.raw[:n]
+
     def comb_table(self, curve) -> bytes:
         size = 2 * self.sb(curve) * 15 * 2 * self.fb(curve)
         out = ctypes.create_string_buffer(size)
