@@ -381,6 +381,49 @@ int eccx_scalarmul_base(eccx_ctx* ctx, int curve, size_t n, const uint8_t* scala
   return run_host(ctx, curve, true, n, scalars, nullptr, out, flags, proj, opts);
 }
 
+int eccx_point_add(eccx_ctx* ctx, int curve, size_t n, const uint8_t* a, const uint8_t* a_inf, const uint8_t* b,
+                   const uint8_t* b_inf, uint8_t* out, uint8_t* flags, uint32_t opts) {
+  const CurveOps* ops = ops_of(curve);
+  if (!ctx) return ECCX_ERR_ARG;
+  if (!ops) return ECCX_ERR_CURVE;
+  if (n == 0) return ECCX_OK;
+  if (!a || !b || !out || !flags) return ECCX_ERR_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t pb = 2 * (size_t)ops->info.fb;
+  uint8_t* d[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // a, b, a_inf, b_inf, out, flags
+  auto cleanup = [&]() {
+    for (auto p : d)
+      if (p) (void)hipFree(p);
+  };
+  auto fail = [&](hipError_t e, const char* what) {
+    ctx->err = std::string(what) + ": " + hipGetErrorString(e);
+    cleanup();
+    return e == hipErrorOutOfMemory ? ECCX_ERR_NOMEM : ECCX_ERR_HIP;
+  };
+  const size_t sizes[6] = {n * pb, n * pb, a_inf ? n : 0, b_inf ? n : 0, n * pb, n};
+  const uint8_t* src[4] = {a, b, a_inf, b_inf};
+  hipError_t e;
+  for (int i = 0; i < 6; ++i)
+    if (sizes[i] && (e = hipMalloc(&d[i], sizes[i])) != hipSuccess) return fail(e, "hipMalloc");
+  for (int i = 0; i < 4; ++i)
+    if (sizes[i] && (e = hipMemcpyAsync(d[i], src[i], sizes[i], hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
+      return fail(e, "hipMemcpyAsync");
+  int rc = ensure_rows(ctx, ops, n);
+  if (rc) { cleanup(); return rc; }
+  size_t need = (n + eccx::LAUNCH_WG - 1) / eccx::LAUNCH_WG;
+  int grid = (int)std::max<size_t>(1, std::min(need, (size_t)ctx->cus * 8));
+  if ((e = ops->point_add(grid, ctx->stream, n, d[0], d[2], d[1], d[3], ctx->jac, d[5],
+                          (opts & ECCX_SUBTRACT) ? (1u << 5) : 0u)) != hipSuccess)
+    return fail(e, "point_add launch");
+  if ((e = ops->to_affine_hom(norm_grid(ctx, n), ctx->stream, n, ctx->jac, d[4], d[5])) != hipSuccess)
+    return fail(e, "to_affine launch");
+  if ((e = hipMemcpyAsync(out, d[4], n * pb, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) return fail(e, "hipMemcpyAsync");
+  if ((e = hipMemcpyAsync(flags, d[5], n, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) return fail(e, "hipMemcpyAsync");
+  if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(e, "hipStreamSynchronize");
+  cleanup();
+  return ECCX_OK;
+}
+
 int eccx_x25519_dev(eccx_ctx* ctx, size_t n, const void* d_scalars, const void* d_u, void* d_out, void* d_flags,
                     uint32_t opts, void* stream) {
   if (!ctx) return ECCX_ERR_ARG;

@@ -386,6 +386,65 @@ __global__ void __launch_bounds__(WG) k_ed_scalarmul_base(size_t n, const uint8_
   }  // grid-stride
 }
 
+// ---- batched group law: out[i] = a[i] + b[i]  (or a[i] - b[i]) -----------------------------
+//   impl Add/Sub/Neg for Point, CurveGroup::double   src/curve/fiat/curve_macros.rs:297-411,
+//   src/curve/group.rs:28-70 -> add_or_double_{am3,a0} (projective.rs:1003-1019) i.e. the
+//   complete RCB addition, which also covers a == b (doubling), a == -b and infinity;
+//   edwards25519: Point::add (curve25519.rs:695-710).
+// Inputs are affine x||y with an optional flag array (1 = point at infinity); results go out
+// as un-normalised rows for k_batch_to_affine.
+enum : uint32_t { OPT_NEGATE_B = 1u << 5 };
+
+template <class C>
+__global__ void __launch_bounds__(WG) k_point_add(size_t n, const uint8_t* __restrict__ a, const uint8_t* __restrict__ a_inf,
+                                                  const uint8_t* __restrict__ b, const uint8_t* __restrict__ b_inf,
+                                                  uint32_t* __restrict__ rows_out, uint8_t* __restrict__ flags,
+                                                  uint32_t opts) {
+  constexpr int L = C::L;
+  constexpr int FB = C::FB;
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n; i += (size_t)gridDim.x * WG) {
+    Pt<C> p, q, r;
+    Fe<L> raw;
+    fe_load_be<C>(raw, a + i * (size_t)(2 * FB)); fe_to_mont<C>(p.x, raw);
+    fe_load_be<C>(raw, a + i * (size_t)(2 * FB) + FB); fe_to_mont<C>(p.y, raw);
+    fe_set<C>(p.z, C::ONE);
+    if (a_inf && a_inf[i] == 1) pt_set_inf<C>(p);
+    fe_load_be<C>(raw, b + i * (size_t)(2 * FB)); fe_to_mont<C>(q.x, raw);
+    fe_load_be<C>(raw, b + i * (size_t)(2 * FB) + FB); fe_to_mont<C>(q.y, raw);
+    fe_set<C>(q.z, C::ONE);
+    if (opts & OPT_NEGATE_B) fe_neg<C>(q.y, q.y);
+    if (b_inf && b_inf[i] == 1) pt_set_inf<C>(q);
+    pt_add<C>(r, p, q);
+    row_store<C>(rows_out + i * (size_t)row_words<L>(), r);
+    flags[i] = 0;
+  }
+}
+
+template <class C>
+__global__ void __launch_bounds__(WG) k_ed_point_add(size_t n, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
+                                                     uint32_t* __restrict__ rows_out, uint8_t* __restrict__ flags,
+                                                     uint32_t opts) {
+  constexpr int L = C::L;
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n; i += (size_t)gridDim.x * WG) {
+    EdPt<C> p, q, r;
+    Fe<L> raw;
+    fe_load_le<C>(raw, a + i * 64); fe_to_mont<C>(p.x, raw);
+    fe_load_le<C>(raw, a + i * 64 + 32); fe_to_mont<C>(p.y, raw);
+    fe_set<C>(p.z, C::ONE);
+    fe_mul<C>(p.t, p.x, p.y);
+    fe_load_le<C>(raw, b + i * 64); fe_to_mont<C>(q.x, raw);
+    fe_load_le<C>(raw, b + i * 64 + 32); fe_to_mont<C>(q.y, raw);
+    if (opts & OPT_NEGATE_B) fe_neg<C>(q.x, q.x);  // -(x, y) = (-x, y) (curve25519.rs:731-738)
+    fe_set<C>(q.z, C::ONE);
+    fe_mul<C>(q.t, q.x, q.y);
+    ed_add<C>(r, p, q);
+    Pt<C> row;
+    row.x = r.x; row.y = r.y; row.z = r.z;
+    row_store<C>(rows_out + i * (size_t)row_words<L>(), row);
+    flags[i] = 0;
+  }
+}
+
 // ---- curve25519 x-only Montgomery ladder (X25519) -------------------------------------
 //   MontgomeryPoint::scale_bytes -> ladder   src/curve/curve25519.rs:535-541, :474-513
 //   protocol::x25519::x25519 (clamp, decode_u)  src/protocol/x25519.rs:14-45   [OPT_X25519_RFC]

@@ -37,6 +37,9 @@ struct CurveOps {
                          uint32_t* rows, uint8_t* flags);
   // batched normalisation of homogeneous rows (mirror / comb kernels run with OPT_OUT_ROWS)
   hipError_t (*to_affine_hom)(int grid, hipStream_t s, size_t n, const uint32_t* rows, uint8_t* out, uint8_t* flags);
+  // batched group law a + b (or a - b) on affine inputs into un-normalised rows
+  hipError_t (*point_add)(int grid, hipStream_t s, size_t n, const uint8_t* a, const uint8_t* a_inf, const uint8_t* b,
+                          const uint8_t* b_inf, uint32_t* rows, uint8_t* flags, uint32_t opts);
 };
 constexpr int TO_AFFINE_U = 8;  // units normalised per lane with one inversion
 

@@ -18,6 +18,7 @@ MIRROR_REFERENCE = 1 << 1
 TABLE_IN_LDS = 1 << 2
 TABLE_IN_L2 = 1 << 3
 X25519_RAW_LADDER = 1 << 4
+SUBTRACT = 1 << 5
 FLAG_FINITE, FLAG_INFINITY, FLAG_REJECTED = 0, 1, 2
 
 
@@ -122,6 +123,21 @@ class Engine:
         self._check(rc)
         res = (out.raw[: n * 2 * fb], flags.raw[:n])
         return res + (proj.raw[: n * _proj_width(cid)],) if want_proj else res
+
+    def point_add(self, curve, a: bytes, b: bytes, *, a_inf: Optional[bytes] = None, b_inf: Optional[bytes] = None,
+                  subtract: bool = False):
+        """Batched group law out[i] = a[i] + b[i] (a[i] - b[i] with subtract=True) on affine points;
+        a_inf / b_inf flag operands that are the point at infinity.  Returns (affine bytes, flags)."""
+        cid = curve_id(curve)
+        fb = field_bytes(cid)
+        if len(a) != len(b) or len(a) % (2 * fb):
+            raise ValueError("a and b must both be n x 2FB bytes")
+        n = len(a) // (2 * fb)
+        out = ctypes.create_string_buffer(max(1, n * 2 * fb))
+        flags = ctypes.create_string_buffer(max(1, n))
+        rc = self._lib.eccx_point_add(self._ctx, cid, n, a, a_inf, b, b_inf, out, flags, SUBTRACT if subtract else 0)
+        self._check(rc)
+        return out.raw[: n * 2 * fb], flags.raw[:n]
 
     def x25519(self, scalars: bytes, u: Optional[bytes] = None, *, raw_ladder: bool = False):
         """X25519 over a batch: returns (n x 32 little-endian u-coordinates, flags).

@@ -82,7 +82,8 @@ enum {
                                      of reading it through L1/L2.  Default for batches >= 2^16.
                                      Same results; see DESIGN.md for the measured difference. */
   ECCX_TABLE_IN_L2 = 1u << 3,    /* never stage the comb table in LDS */
-  ECCX_X25519_RAW_LADDER = 1u << 4 /* eccx_x25519: raw MontgomeryPoint::scale_bytes semantics */
+  ECCX_X25519_RAW_LADDER = 1u << 4, /* eccx_x25519: raw MontgomeryPoint::scale_bytes semantics */
+  ECCX_SUBTRACT = 1u << 5          /* eccx_point_add: compute a - b */
 };
 
 /* flag values written per unit */
@@ -121,6 +122,17 @@ int eccx_scalarmul_var_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_sca
                            void* d_out, void* d_flags, void* d_proj, uint32_t opts, void* stream);
 int eccx_scalarmul_base_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_scalars, void* d_out,
                             void* d_flags, void* d_proj, uint32_t opts, void* stream);
+
+/* Group law on batches: out[i] = a[i] + b[i], or a[i] - b[i] with ECCX_SUBTRACT.
+ * Mirrors impl Add / Sub / Neg for Point and CurveGroup::double
+ * (src/curve/fiat/curve_macros.rs:297-411, src/curve/group.rs:28-70): the complete addition
+ * (projective.rs:340-423 / :268-338; curve25519.rs:695-710) covers a == b, a == -b and the
+ * point at infinity, so double(a) is eccx_point_add(a, a) and neg(a) is infinity - a.
+ *   a, b        : n x 2FB affine x||y (host memory)
+ *   a_inf, b_inf: NULL, or n flag bytes (1 = that operand is the point at infinity; Weierstrass only)
+ *   out, flags  : as for eccx_scalarmul_var */
+int eccx_point_add(eccx_ctx* ctx, int curve, size_t n, const uint8_t* a, const uint8_t* a_inf, const uint8_t* b,
+                   const uint8_t* b_inf, uint8_t* out, uint8_t* flags, uint32_t opts);
 
 /* X25519: the curve25519 x-only Montgomery ladder.
  *   default            protocol::x25519::x25519 (src/protocol/x25519.rs:36-45): `scalars` are

@@ -40,6 +40,13 @@ int main() {
         return 1;
       }
     }
+    // CurveGroup::double and Add: 2*G == G + G == G.dbl(), and (k*G) - (k*G) is infinity
+    auto two_g = gen.dbl(eng).to_affine();
+    auto g_plus_g = gen.add(eng, gen).to_affine();
+    if (std::memcmp(two_g.x(5), a.x(2), 64) || std::memcmp(g_plus_g.x(7), a.x(2), 64)) { std::puts("FAIL: G + G != 2*G"); return 1; }
+    auto zero = base.sub(eng, var).to_affine();
+    for (size_t i = 0; i < n; ++i)
+      if (!zero.is_infinity(i)) { std::printf("FAIL: P - P is not infinity at %zu\n", i); return 1; }
     std::puts("mirror_check ok");
     return 0;
   } catch (const std::exception& e) {
