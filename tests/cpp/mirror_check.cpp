@@ -26,6 +26,7 @@ int main() {
     }
     std::memset(&k[0], 0, C::SB);                       // unit 0: scalar 0 -> infinity
     std::memset(&k[C::SB], 0, C::SB); k[C::SB + 31] = 1; // unit 1: scalar 1 -> G
+    std::memset(&k[2 * C::SB], 0, C::SB); k[2 * C::SB + 31] = 2; // unit 2: scalar 2 -> 2G
     auto scalars = eccx::Scalars<C>::from_bytes(k.data(), n);
     auto base = eccx::Points<C>::mul_base(eng, scalars);
     auto gen = eccx::Points<C>::from_affine(eccx::PointsAffine<C>::from_coordinates(g.data(), n));
