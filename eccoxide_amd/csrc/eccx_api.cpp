@@ -90,7 +90,8 @@ int ensure_buffer(eccx_ctx* ctx, uint32_t** buf, size_t* have, size_t words) {
 }
 
 int ensure_scratch(eccx_ctx* ctx, int row_words, int grid) {
-  size_t words = (size_t)grid * 16 * eccx::LAUNCH_WG * (size_t)row_words;
+  // 17 rows per lane: the signed-window table of the fast kernel holds entries 1..16
+  size_t words = (size_t)grid * 17 * eccx::LAUNCH_WG * (size_t)row_words;
   std::lock_guard<std::mutex> g(ctx->scratch_mu);
   return ensure_buffer(ctx, &ctx->scratch, &ctx->scratch_words, words);
 }
@@ -113,8 +114,10 @@ int norm_grid(const eccx_ctx* ctx, size_t n) {
 int launch_var(eccx_ctx* ctx, const CurveOps* ops, size_t n, const uint8_t* d_scalars, const uint8_t* d_points,
                uint8_t* d_out, uint8_t* d_flags, uint8_t* d_proj, uint32_t kopts, bool mirror, hipStream_t s) {
   if (n == 0) return ECCX_OK;
-  int grid = grid_for(ctx, n);
   const bool fast = !mirror && ops->var_fast && !d_proj && !(kopts & K_OUT_TABLE);
+  // persistent grid sized to the kernel's real residency (registers decide it)
+  int grid = fast ? (ops->var_fast_grid ? ops->var_fast_grid(ctx->cus, n) : grid_for(ctx, n))
+                  : (ops->var_grid ? ops->var_grid(ctx->cus, n) : grid_for(ctx, n));
   if (fast) {
     int rc = ensure_scratch(ctx, ops->info.row5_words, grid);
     if (rc) return rc;

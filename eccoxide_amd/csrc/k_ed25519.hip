@@ -30,6 +30,10 @@ hipError_t to_affine_hom_(int grid, hipStream_t s, size_t n, const uint32_t* row
   hipLaunchKernelGGL((k_batch_to_affine<ED25519, NORM_EDWARDS, TO_AFFINE_U>), dim3(grid), dim3(WG), 0, s, n, rows, out, flags);
   return hipGetLastError();
 }
+int var_grid_(int cus, size_t n) {
+  static const int occ = occupancy_per_cu(k_ed_scalarmul_var<ED25519>);
+  return persistent_grid(occ, cus, n);
+}
 hipError_t point_add_(int grid, hipStream_t s, size_t n, const uint8_t* a, const uint8_t* /*a_inf*/, const uint8_t* b,
                       const uint8_t* /*b_inf*/, uint32_t* rows, uint8_t* flags, uint32_t opts) {
   hipLaunchKernelGGL(k_ed_point_add<ED25519>, dim3(grid), dim3(WG), 0, s, n, a, b, rows, flags, opts);
@@ -47,7 +51,7 @@ hipError_t launch_x25519_to_u(int grid, hipStream_t s, size_t n, const uint32_t*
   return hipGetLastError();
 }
 const CurveOps& ops_ED25519() {
-  static const CurveOps o = {{ED25519::FB, ED25519::SB, ED25519::L, 4 * ED25519::L, 0, 1, 0, row_words<ED25519::L>()}, var_, base_, nullptr, nullptr, nullptr, base_lds_, to_affine_hom_, point_add_};
+  static const CurveOps o = {{ED25519::FB, ED25519::SB, ED25519::L, 4 * ED25519::L, 0, 1, 0, row_words<ED25519::L>()}, var_, base_, nullptr, nullptr, nullptr, base_lds_, to_affine_hom_, var_grid_, nullptr, point_add_};
   return o;
 }
 }  // namespace eccx

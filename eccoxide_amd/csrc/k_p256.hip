@@ -32,6 +32,14 @@ hipError_t to_affine_hom_(int grid, hipStream_t s, size_t n, const uint32_t* row
   hipLaunchKernelGGL((k_batch_to_affine<P256, NORM_HOMOGENEOUS, TO_AFFINE_U>), dim3(grid), dim3(WG), 0, s, n, rows, out, flags);
   return hipGetLastError();
 }
+int var_grid_(int cus, size_t n) {
+  static const int occ = occupancy_per_cu(k_scalarmul_var<P256>);
+  return persistent_grid(occ, cus, n);
+}
+int var_fast_grid_(int cus, size_t n) {
+  static const int occ = occupancy_per_cu(k_scalarmul_var_fast<P256>);
+  return persistent_grid(occ, cus, n);
+}
 hipError_t point_add_(int grid, hipStream_t s, size_t n, const uint8_t* a, const uint8_t* a_inf, const uint8_t* b,
                       const uint8_t* b_inf, uint32_t* rows, uint8_t* flags, uint32_t opts) {
   hipLaunchKernelGGL(k_point_add<P256>, dim3(grid), dim3(WG), 0, s, n, a, a_inf, b, b_inf, rows, flags, opts);
@@ -39,7 +47,7 @@ hipError_t point_add_(int grid, hipStream_t s, size_t n, const uint8_t* a, const
 }
 }  // namespace
 const CurveOps& ops_P256() {
-  static const CurveOps o = {{P256::FB, P256::SB, P256::L, 2 * P256::L, row_words<P256::L>(), 0, row5_words<P256::L>(), row_words<P256::L>()}, var_, base_, var_fast_, to_affine_jac_, base_fast_, nullptr, to_affine_hom_, point_add_};
+  static const CurveOps o = {{P256::FB, P256::SB, P256::L, 2 * P256::L, row_words<P256::L>(), 0, row5_words<P256::L>(), row_words<P256::L>()}, var_, base_, var_fast_, to_affine_jac_, base_fast_, nullptr, to_affine_hom_, var_grid_, var_fast_grid_, point_add_};
   return o;
 }
 }  // namespace eccx

@@ -2,10 +2,11 @@
 //
 //   k_scalarmul_var_fast<C>  same contract as k_scalarmul_var<C> (kernels.hpp) -- the
 //       reference's &Point * &Scalar, src/curve/fiat/curve_macros.rs:321-327 -- but on
-//       Jacobian coordinates (curve_fast.hpp).  Same 4-bit fixed window and digit order as
-//       scalar_mul_fixed_window (src/curve/projective.rs:871-896): table d*P, d = 1..15, then
-//       per nibble (MSB first) 4 doublings + 1 addition.  Writes the un-normalised Jacobian
-//       result per unit; flags[i] = 2 for rejected inputs, 0 otherwise.
+//       Jacobian coordinates (curve_fast.hpp) and with signed 5-bit windows (Booth recoding):
+//       table d*P, d = 1..16, then per window (MSB first) 5 doublings + 1 addition of +-d*P.
+//       The reference's fixed 4-bit unsigned window (src/curve/projective.rs:871-896) needs
+//       2*SB additions, this needs ceil((8*SB + 1)/5); k*P is the same point either way.
+//       Writes the un-normalised Jacobian result per unit; flags[i] = 2 for rejected inputs.
 //   k_batch_to_affine<C>     Point::to_affine (projective.rs:655-682) for a whole batch: each
 //       lane normalises U units with ONE field inversion (Montgomery's trick), so the
 //       ~380-multiplication Fermat inversion is paid once per 8 units instead of per unit.
@@ -23,6 +24,8 @@ namespace eccx {
 
 template <int L>
 constexpr int row5_words() { return ((5 * L + 3) / 4) * 4; }
+
+constexpr int FAST_TABLE_ROWS = 17;  // entries 1..16 of the signed 5-bit window table (+ unused row 0)
 
 template <class C>
 ECCX_DEV void entry_store(uint32_t* __restrict__ row, const JacEntry<C>& p) {
@@ -65,11 +68,11 @@ __global__ void __launch_bounds__(WG) k_scalarmul_var_fast(size_t n, const uint8
   constexpr int L = C::L;
   constexpr int FB = C::FB;
   constexpr int SB = C::SB;
-  constexpr int NW = 2 * SB;
+  constexpr int NWIN = (8 * SB + 1 + 4) / 5;  // signed 5-bit windows covering 8*SB + 1 bits
   constexpr int W5 = row5_words<L>();
   constexpr int W3 = row_words<L>();
-  // per-lane window table: [workgroup][entry 1..15][thread][W5 words] (entry 0 unused)
-  uint32_t* slab = scratch + ((size_t)blockIdx.x * 16 * WG + threadIdx.x) * (size_t)W5;
+  // per-lane window table: [workgroup][entry 1..16][thread][W5 words] (entry 0 unused)
+  uint32_t* slab = scratch + ((size_t)blockIdx.x * FAST_TABLE_ROWS * WG + threadIdx.x) * (size_t)W5;
   auto row = [&](uint32_t e) { return slab + (size_t)e * WG * W5; };
   for (size_t base = (size_t)blockIdx.x * WG; base < n; base += (size_t)gridDim.x * WG) {
     const size_t gid = base + threadIdx.x;
@@ -99,13 +102,13 @@ __global__ void __launch_bounds__(WG) k_scalarmul_var_fast(size_t n, const uint8
     }
     const uint8_t* __restrict__ k = scalars + idx * (size_t)SB;
 
-    int b = 0;            // table-build step: 0 -> T[2] = 2P, 1..13 -> T[b+2] = T[b+1] + P
-    int win = 0, sub = 0; // main loop position
+    int b = 0;                    // table-build step: 0 -> T[2] = 2P, 1..14 -> T[b+2] = T[b+1] + P
+    int win = NWIN - 1, sub = 5;  // main loop position; the top window needs no doublings
     bool fix_pending = false, fix_lane = false;
     for (;;) {
-      const bool building = b < 14;
-      if (!building && win == NW) break;
-      const bool do_dbl = fix_pending || (building ? (b == 0) : (sub < 4));
+      const bool building = b < 15;
+      if (!building && win < 0) break;
+      const bool do_dbl = fix_pending || (building ? (b == 0) : (sub < 5));
       bool step_done;
       if (do_dbl) {
         Jac<C> t;
@@ -120,12 +123,26 @@ __global__ void __launch_bounds__(WG) k_scalarmul_var_fast(size_t n, const uint8
         step_done = true;
       } else {
         uint32_t d = 1;
+        bool neg = false;
         if (!building) {
-          uint32_t byte = k[win >> 1];
-          d = (win & 1) ? (byte & 0x0f) : (byte >> 4);
+          // Booth digit of window `win`: bits [5*win - 1, 5*win + 4] of the scalar (bit -1 = 0)
+          const int pos = 5 * win - 1 + 8;  // bit position in a string with one extra zero byte below
+          const int bi = pos >> 3;          // byte 0 is that extra byte, byte j >= 1 is k[SB - j]
+          const uint32_t b0 = (bi >= 1 && bi <= SB) ? k[SB - bi] : 0u;
+          const uint32_t b1 = (bi + 1 <= SB) ? k[SB - bi - 1] : 0u;
+          const uint32_t w6 = ((b0 | (b1 << 8)) >> (pos & 7)) & 0x3fu;
+          const uint32_t s = ~((w6 >> 5) - 1u);  // all ones when the window's top bit is set
+          uint32_t m = (((1u << 6) - w6 - 1u) & s) | (w6 & ~s);
+          d = (m >> 1) + (m & 1u);               // |digit| in 0..16
+          neg = (s & 1u) != 0;
         }
         JacEntry<C> e;
         entry_load<C>(e, row(d ? d : 1));
+        {
+          Fe<L> ny;
+          fe_neg<C>(ny, e.y);
+          fe_select<C>(e.y, neg, ny, e.y);
+        }
         const bool q_inf = fe_is_zero<C>(q.z);
         const bool e_skip = (d == 0) || fe_is_zero<C>(e.z);
         Jac<C> sum;
@@ -149,12 +166,12 @@ __global__ void __launch_bounds__(WG) k_scalarmul_var_fast(size_t n, const uint8
           fe_sqr<C>(e.zz, q.z);
           fe_mul<C>(e.zzz, e.zz, q.z);
           entry_store<C>(row(b + 2), e);
-          if (++b == 14) fe_zero<C>(q.z);  // accumulator starts at infinity
-        } else if (sub < 4) {
+          if (++b == 15) fe_zero<C>(q.z);  // accumulator starts at infinity
+        } else if (sub < 5) {
           ++sub;
         } else {
           sub = 0;
-          ++win;
+          --win;
         }
       }
     }

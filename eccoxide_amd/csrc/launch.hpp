@@ -37,6 +37,10 @@ struct CurveOps {
                          uint32_t* rows, uint8_t* flags);
   // batched normalisation of homogeneous rows (mirror / comb kernels run with OPT_OUT_ROWS)
   hipError_t (*to_affine_hom)(int grid, hipStream_t s, size_t n, const uint32_t* rows, uint8_t* out, uint8_t* flags);
+  // persistent-grid sizes of the variable-base kernels: min(workgroups needed, CUs x resident
+  // workgroups per CU from the occupancy query), so no workgroup waits for a slot
+  int (*var_grid)(int cus, size_t n);
+  int (*var_fast_grid)(int cus, size_t n);
   // batched group law a + b (or a - b) on affine inputs into un-normalised rows
   hipError_t (*point_add)(int grid, hipStream_t s, size_t n, const uint8_t* a, const uint8_t* a_inf, const uint8_t* b,
                           const uint8_t* b_inf, uint32_t* rows, uint8_t* flags, uint32_t opts);
@@ -55,5 +59,18 @@ hipError_t launch_x25519_ladder(int grid, hipStream_t s, size_t n, const uint8_t
 hipError_t launch_x25519_to_u(int grid, hipStream_t s, size_t n, const uint32_t* rows, uint8_t* out, uint8_t* flags);
 
 constexpr int LAUNCH_WG = 256;
+
+template <class K>
+inline int occupancy_per_cu(K kernel) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, LAUNCH_WG, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+  return per_cu;
+}
+inline int persistent_grid(int per_cu, int cus, size_t n) {
+  size_t need = (n + LAUNCH_WG - 1) / LAUNCH_WG;
+  size_t cap = (size_t)cus * (size_t)per_cu;
+  size_t g = need < cap ? need : cap;
+  return (int)(g ? g : 1);
+}
 
 }  // namespace eccx

@@ -120,7 +120,14 @@ def test_fast_ladder_exceptional_cases(engine, oracle, curve):
     order = W.order(curve)
     d = (-order) % 16
     assert d != 0
-    vals = [order + 2 * d, order, order + 1, order + 16, 1 << 4, 1 << 8, (1 << 12) + 1, 0x1001 << 64,
+    # the default kernel uses signed 5-bit windows: the same construction with radix 32 and a
+    # signed last digit e in [-15, 16]: 32*a = n + e, k = 32*a + e = n + 2e
+    e = (-order) % 32
+    if e > 16:
+        e -= 32
+    vals = [order + 2 * d, order + 2 * e, order - 2 * e, order, order + 1, order - 1, order + 16, order + 32,
+            1 << 4, 1 << 5, 1 << 8, 1 << 10, (1 << 12) + 1, (1 << 15) + 17, 0x1001 << 64,
+            31, 32, 33, 16, 17, 48, 0x210 << 40,
             2 * order + 4 * d if 2 * order + 4 * d < (1 << (8 * sb)) else order + 2 * d]
     if curve == "p521r1":
         vals += [(order + 2 * d) * 16 + 5, (order + 2 * d) * 256 + 0x50]
