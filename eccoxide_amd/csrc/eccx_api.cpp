@@ -427,6 +427,53 @@ int eccx_point_add(eccx_ctx* ctx, int curve, size_t n, const uint8_t* a, const u
   return ECCX_OK;
 }
 
+int eccx_double_scalarmul(eccx_ctx* ctx, int curve, size_t n, const uint8_t* u1, const uint8_t* u2,
+                          const uint8_t* q, uint8_t* out, uint8_t* flags, uint32_t opts) {
+  const CurveOps* ops = ops_of(curve);
+  if (!ctx) return ECCX_ERR_ARG;
+  if (!ops) return ECCX_ERR_CURVE;
+  if (n == 0) return ECCX_OK;
+  if (!u1 || !u2 || !q || !out || !flags) return ECCX_ERR_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t pb = 2 * (size_t)ops->info.fb, sb = (size_t)ops->info.sb;
+  // device buffers: u1, u2, q, A = u1*G, fA, B = u2*Q, fB, out, flags
+  uint8_t* d[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  const size_t sizes[9] = {n * sb, n * sb, n * pb, n * pb, n, n * pb, n, n * pb, n};
+  auto cleanup = [&]() {
+    for (auto p : d)
+      if (p) (void)hipFree(p);
+  };
+  auto fail = [&](hipError_t e, const char* what) {
+    ctx->err = std::string(what) + ": " + hipGetErrorString(e);
+    cleanup();
+    return e == hipErrorOutOfMemory ? ECCX_ERR_NOMEM : ECCX_ERR_HIP;
+  };
+  hipError_t e;
+  for (int i = 0; i < 9; ++i)
+    if ((e = hipMalloc(&d[i], sizes[i])) != hipSuccess) return fail(e, "hipMalloc");
+  const uint8_t* src[3] = {u1, u2, q};
+  for (int i = 0; i < 3; ++i)
+    if ((e = hipMemcpyAsync(d[i], src[i], sizes[i], hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
+      return fail(e, "hipMemcpyAsync");
+  int rc = eccx_scalarmul_base_dev(ctx, curve, n, d[0], d[3], d[4], nullptr, 0, ctx->stream);
+  if (!rc) rc = eccx_scalarmul_var_dev(ctx, curve, n, d[1], d[2], d[5], d[6], nullptr, opts & ECCX_VALIDATE_POINTS, ctx->stream);
+  if (rc) { cleanup(); return rc; }
+  rc = ensure_rows(ctx, ops, n);
+  if (rc) { cleanup(); return rc; }
+  size_t need = (n + eccx::LAUNCH_WG - 1) / eccx::LAUNCH_WG;
+  int grid = (int)std::max<size_t>(1, std::min(need, (size_t)ctx->cus * 8));
+  if ((e = ops->point_add(grid, ctx->stream, n, d[3], d[4], d[5], d[6], ctx->jac, d[8],
+                          (opts & ECCX_SUBTRACT) ? (1u << 5) : 0u)) != hipSuccess)
+    return fail(e, "point_add launch");
+  if ((e = ops->to_affine_hom(norm_grid(ctx, n), ctx->stream, n, ctx->jac, d[7], d[8])) != hipSuccess)
+    return fail(e, "to_affine launch");
+  if ((e = hipMemcpyAsync(out, d[7], n * pb, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) return fail(e, "hipMemcpyAsync");
+  if ((e = hipMemcpyAsync(flags, d[8], n, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) return fail(e, "hipMemcpyAsync");
+  if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(e, "hipStreamSynchronize");
+  cleanup();
+  return ECCX_OK;
+}
+
 int eccx_x25519_dev(eccx_ctx* ctx, size_t n, const void* d_scalars, const void* d_u, void* d_out, void* d_flags,
                     uint32_t opts, void* stream) {
   if (!ctx) return ECCX_ERR_ARG;

@@ -34,9 +34,9 @@ int var_grid_(int cus, size_t n) {
   static const int occ = occupancy_per_cu(k_ed_scalarmul_var<ED25519>);
   return persistent_grid(occ, cus, n);
 }
-hipError_t point_add_(int grid, hipStream_t s, size_t n, const uint8_t* a, const uint8_t* /*a_inf*/, const uint8_t* b,
-                      const uint8_t* /*b_inf*/, uint32_t* rows, uint8_t* flags, uint32_t opts) {
-  hipLaunchKernelGGL(k_ed_point_add<ED25519>, dim3(grid), dim3(WG), 0, s, n, a, b, rows, flags, opts);
+hipError_t point_add_(int grid, hipStream_t s, size_t n, const uint8_t* a, const uint8_t* a_fl, const uint8_t* b,
+                      const uint8_t* b_fl, uint32_t* rows, uint8_t* flags, uint32_t opts) {
+  hipLaunchKernelGGL(k_ed_point_add<ED25519>, dim3(grid), dim3(WG), 0, s, n, a, a_fl, b, b_fl, rows, flags, opts);
   return hipGetLastError();
 }
 }  // namespace

@@ -416,12 +416,13 @@ __global__ void __launch_bounds__(WG) k_point_add(size_t n, const uint8_t* __res
     if (b_inf && b_inf[i] == 1) pt_set_inf<C>(q);
     pt_add<C>(r, p, q);
     row_store<C>(rows_out + i * (size_t)row_words<L>(), r);
-    flags[i] = 0;
+    flags[i] = ((a_inf && a_inf[i] == 2) || (b_inf && b_inf[i] == 2)) ? 2 : 0;  // rejected operands stay rejected
   }
 }
 
 template <class C>
-__global__ void __launch_bounds__(WG) k_ed_point_add(size_t n, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
+__global__ void __launch_bounds__(WG) k_ed_point_add(size_t n, const uint8_t* __restrict__ a, const uint8_t* __restrict__ a_fl,
+                                                     const uint8_t* __restrict__ b, const uint8_t* __restrict__ b_fl,
                                                      uint32_t* __restrict__ rows_out, uint8_t* __restrict__ flags,
                                                      uint32_t opts) {
   constexpr int L = C::L;
@@ -441,7 +442,7 @@ __global__ void __launch_bounds__(WG) k_ed_point_add(size_t n, const uint8_t* __
     Pt<C> row;
     row.x = r.x; row.y = r.y; row.z = r.z;
     row_store<C>(rows_out + i * (size_t)row_words<L>(), row);
-    flags[i] = 0;
+    flags[i] = ((a_fl && a_fl[i] == 2) || (b_fl && b_fl[i] == 2)) ? 2 : 0;
   }
 }
 

@@ -139,6 +139,22 @@ class Engine:
         self._check(rc)
         return out.raw[: n * 2 * fb], flags.raw[:n]
 
+    def double_scalarmul(self, curve, u1: bytes, u2: bytes, q: bytes, *, subtract: bool = False,
+                         validate: bool = False):
+        """out[i] = u1[i]*G + u2[i]*q[i] (minus with subtract=True): the signature-verification
+        shape (ECDSA u1*G + u2*Q, Ed25519 [s]B - [k]A).  Returns (affine bytes, flags)."""
+        cid = curve_id(curve)
+        sb, fb = scalar_bytes(cid), field_bytes(cid)
+        if len(u1) != len(u2) or len(u1) % sb or len(q) != (len(u1) // sb) * 2 * fb:
+            raise ValueError("u1, u2 must be n x SB bytes and q n x 2FB bytes")
+        n = len(u1) // sb
+        out = ctypes.create_string_buffer(max(1, n * 2 * fb))
+        flags = ctypes.create_string_buffer(max(1, n))
+        rc = self._lib.eccx_double_scalarmul(self._ctx, cid, n, u1, u2, q, out, flags,
+                                             (SUBTRACT if subtract else 0) | (VALIDATE_POINTS if validate else 0))
+        self._check(rc)
+        return out.raw[: n * 2 * fb], flags.raw[:n]
+
     def x25519(self, scalars: bytes, u: Optional[bytes] = None, *, raw_ladder: bool = False):
         """X25519 over a batch: returns (n x 32 little-endian u-coordinates, flags).
         Default: RFC 7748 semantics (protocol::x25519::x25519): little-endian scalars, clamped;

@@ -134,6 +134,16 @@ int eccx_scalarmul_base_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_sc
 int eccx_point_add(eccx_ctx* ctx, int curve, size_t n, const uint8_t* a, const uint8_t* a_inf, const uint8_t* b,
                    const uint8_t* b_inf, uint8_t* out, uint8_t* flags, uint32_t opts);
 
+/* Double-scalar "verify shape": out[i] = u1[i]*G + u2[i]*Q[i]  (u1*G - u2*Q with ECCX_SUBTRACT).
+ * The batched form of ECDSA verification's u1*G + u2*Q (src/protocol/ecdsa.rs:215) and of
+ * Ed25519's [s]B - [k]A (src/protocol/ed25519.rs:145; the reference uses the variable-time
+ * double_scalar_mul_base_vartime, src/curve/curve25519.rs:1157-1183 -- same point).  Composed on
+ * the device from the fixed-base comb, the variable-base ladder and the complete addition.
+ *   u1, u2 : n x SB scalars      q : n x 2FB affine points      out, flags: as above
+ * ECCX_VALIDATE_POINTS applies to q. */
+int eccx_double_scalarmul(eccx_ctx* ctx, int curve, size_t n, const uint8_t* u1, const uint8_t* u2,
+                          const uint8_t* q, uint8_t* out, uint8_t* flags, uint32_t opts);
+
 /* X25519: the curve25519 x-only Montgomery ladder.
  *   default            protocol::x25519::x25519 (src/protocol/x25519.rs:36-45): `scalars` are
  *                      n x 32 little-endian RFC 7748 scalars, clamped on use (x25519.rs:15-20);

@@ -1,0 +1,88 @@
+"""Double-scalar "verify shape" u1*G + u2*Q: ECDSA verification of the
+RFC 6979 signatures the reference's tests hold (src/protocol/ecdsa.rs:808-915, verify :197-233),
+Ed25519's [s]B - [k]A, and random batches against the big-int oracle."""
+import hashlib
+import random
+
+import pytest
+
+from eccoxide_amd import workload as W
+from oracle import ecc_ref as R
+from tests.oracle_lib import golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("curve", ["p256r1", "p384r1", "p521r1"])
+def test_ecdsa_verify_rfc6979_signatures(engine, curve):
+    """verify: w = s^-1, u1 = e*w, u2 = r*w, accept iff x(u1*G + u2*Q) mod n == r."""
+    c = R.CURVES[curve]
+    v = golden("rfc6979.json")[curve]
+    q = bytes.fromhex(v["ux"].rjust(2 * c.fb, "0")) + bytes.fromhex(v["uy"].rjust(2 * c.fb, "0"))
+    u1s, u2s, rs = b"", b"", []
+    for kat in v["sign_kats"]:
+        h = getattr(hashlib, kat["alg"])(kat["message"].encode()).digest()
+        e = int.from_bytes(h, "big")
+        if 8 * len(h) > c.n.bit_length():                  # bits2int: keep the leftmost qlen bits
+            e >>= 8 * len(h) - c.n.bit_length()
+        r, s = int(kat["r"], 16), int(kat["s"], 16)
+        w = pow(s, -1, c.n)
+        u1s += (e * w % c.n).to_bytes(c.sb, "big")
+        u2s += (r * w % c.n).to_bytes(c.sb, "big")
+        rs.append(r)
+    n = len(rs)
+    out, flags = engine.double_scalarmul(curve, u1s, u2s, q * n)
+    for i, r in enumerate(rs):
+        assert flags[i] == 0
+        assert int.from_bytes(out[i * 2 * c.fb: i * 2 * c.fb + c.fb], "big") % c.n == r
+    # a tampered signature does not verify
+    bad = bytearray(u2s)
+    bad[-1] ^= 1
+    out, flags = engine.double_scalarmul(curve, u1s, bytes(bad), q * n)
+    assert all(int.from_bytes(out[i * 2 * c.fb: i * 2 * c.fb + c.fb], "big") % c.n != r for i, r in enumerate(rs))
+
+
+@pytest.mark.parametrize("curve", ["p256r1", "bls12_381_g1"])
+def test_double_scalarmul_matches_oracle(engine, oracle, curve):
+    c = R.CURVES[curve]
+    n = 48
+    u1 = W.random_scalars(curve, n, seed=71).tobytes()
+    u2 = bytearray(W.random_scalars(curve, n, seed=72).tobytes())
+    q = oracle.base(curve, W.random_scalars(curve, n, seed=73).tobytes())[0]
+    u2[0:c.sb] = bytes(c.sb)                                # u2 = 0: result u1*G
+    u1b = bytearray(u1)
+    u1b[c.sb:2 * c.sb] = bytes(c.sb)                        # u1 = 0: result u2*Q
+    u1, u2 = bytes(u1b), bytes(u2)
+    A = oracle.base(curve, u1)
+    B = oracle.var(curve, u2, q)
+    pb = 2 * c.fb
+
+    def pt(buf, fl, i):
+        return None if fl[i] else (int.from_bytes(buf[i * pb:i * pb + c.fb], "big"), int.from_bytes(buf[i * pb + c.fb:(i + 1) * pb], "big"))
+
+    for subtract in (False, True):
+        out, flags = engine.double_scalarmul(curve, u1, u2, q, subtract=subtract)
+        for i in range(n):
+            P, Q = pt(A[0], A[1], i), pt(B[0], B[1], i)
+            if subtract and Q is not None:
+                Q = (Q[0], (-Q[1]) % c.p)
+            want = R.affine_add(c, P, Q)
+            enc = bytes(pb) if want is None else want[0].to_bytes(c.fb, "big") + want[1].to_bytes(c.fb, "big")
+            assert out[i * pb:(i + 1) * pb] == enc and flags[i] == (1 if want is None else 0)
+
+
+def test_ed25519_verify_shape(engine, oracle):
+    """[s]B - [k]A == R for honest signatures: with A = a*B, R = r*B and s = r + k*a (mod l)
+    (src/protocol/ed25519.rs:91-112 sign, :127-150 verify)."""
+    c = R.ED25519
+    rng = random.Random(8032)
+    n = 64
+    a = [rng.randrange(1, c.n) for _ in range(n)]
+    r = [rng.randrange(1, c.n) for _ in range(n)]
+    k = [rng.randrange(1, c.n) for _ in range(n)]
+    s = [(ri + ki * ai) % c.n for ri, ki, ai in zip(r, k, a)]
+    be = lambda xs: b"".join(x.to_bytes(32, "big") for x in xs)
+    A = oracle.base("ed25519", be(a))[0]
+    Rpt = oracle.base("ed25519", be(r))[0]
+    out, flags = engine.double_scalarmul("ed25519", be(s), be(k), A, subtract=True)
+    assert out == Rpt and flags == bytes(n)
