@@ -37,7 +37,8 @@ def test_ecdsa_verify_rfc6979_signatures(engine, curve):
         assert int.from_bytes(out[i * 2 * c.fb: i * 2 * c.fb + c.fb], "big") % c.n == r
     # a tampered signature does not verify
     bad = bytearray(u2s)
-    bad[-1] ^= 1
+    for i in range(n):
+        bad[(i + 1) * c.sb - 1] ^= 1
     out, flags = engine.double_scalarmul(curve, u1s, bytes(bad), q * n)
     assert all(int.from_bytes(out[i * 2 * c.fb: i * 2 * c.fb + c.fb], "big") % c.n != r for i, r in enumerate(rs))
 
