@@ -29,10 +29,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 def _var_muls(nw, dbl, inv):
-    """field mul+sqr the default (Jacobian) variable-base path issues per unit: window table
-    (1 doubling + 13 additions + Z^2, Z^3 per entry), nw windows of 4 doublings + 1 addition,
-    input conversion, and the batched normalisation (one Fermat inversion per 8 units)."""
-    return (dbl + 13 * 14 + 14 * 2) + nw * (4 * dbl + 14) + 2 + (inv + 7) // 8 + 9
+    """field mul+sqr the default (Jacobian, signed 5-bit window) variable-base path issues per
+    unit: window table (1 doubling + 14 additions + Z^2, Z^3 per entry), ceil((4*nw + 1)/5)
+    windows of 5 doublings + 1 addition (no doublings for the top window), input conversion,
+    and the batched normalisation (one Fermat inversion per 8 units)."""
+    nwin = (4 * nw + 1 + 4) // 5
+    return (dbl + 14 * 14 + 15 * 2) + nwin * 14 + (nwin - 1) * 5 * dbl + 2 + (inv + 7) // 8 + 9
 
 
 WORKLOADS = {
