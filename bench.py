@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="p256r1_var_2^20", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=1 << 16)
+    ap.add_argument("--cpu-sample", type=int, default=1 << 17)
     ap.add_argument("--variant", default="default", choices=["default", "mirror", "lds", "l2"],
                     help="default: fast kernels; mirror: reference-mirroring kernels; "
                          "lds / l2: ed25519 fixed base with the comb table forced into LDS / read through L2")
