@@ -53,12 +53,15 @@ WORKLOADS = {
 # read from inside this process, so the figure is the committed measurement of this very
 # workload, not a live one; null where no profile has been taken.
 MEASURED_TRAFFIC = {
-    "p256r1_var_2^20": {"bytes": 2 * (8623171755 + 113180041) + 2618476944 + 105923264,
-                        "fetch_raw": 8623171755 + 113180041, "write": 2618476944 + 105923264,
+    "p256r1_var_2^20": {"bytes": 2 * (6979719147 + 113191515) + 2793436699 + 105929362,
+                        "fetch_raw": 6979719147 + 113191515, "write": 2793436699 + 105929362,
                         "source": "profiles/r01_p256r1_var_fast.json"},
-    "ed25519_base_2^20": {"bytes": 2 * (23648203 + 112667744) + 117058688 + 105948448,
-                          "fetch_raw": 23648203 + 112667744, "write": 117058688 + 105948448,
+    "ed25519_base_2^20": {"bytes": 2 * (23534773 + 112726219) + 117074368 + 105956811,
+                          "fetch_raw": 23534773 + 112726219, "write": 117074368 + 105956811,
                           "source": "profiles/r01_ed25519_base.json"},
+    "x25519_2^20": {"bytes": 2 * (31294638 + 111890286) + 101712549 + 72351863,
+                    "fetch_raw": 31294638 + 111890286, "write": 101712549 + 72351863,
+                    "source": "profiles/r01_x25519.json"},
 }
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # v_mad_u64_u32 issue peak measured by tools/ubench/valu_rates.hip on MI355X
