@@ -82,6 +82,16 @@ def main():
                          "lds / l2: ed25519 fixed base with the comb table forced into LDS / read through L2")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched by hand without torch.distributed.run: start the ranks as a child job
+        # (before anything in this process touches the GPU) and exit with its code
+        import subprocess
+
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
     import torch
     import torch.distributed as dist
 

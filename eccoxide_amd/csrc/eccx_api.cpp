@@ -156,23 +156,45 @@ std::vector<uint8_t> comb_scalars(const CurveOps* ops) {
   return k;
 }
 
+// device allocations scoped to one call: freed on every return path
+struct DevMem {
+  std::vector<void*> ptrs;
+  ~DevMem() {
+    for (void* p : ptrs)
+      if (p) (void)hipFree(p);
+  }
+  template <class T>
+  hipError_t alloc(T** out, size_t bytes) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipSuccess) ptrs.push_back(p);
+    *out = static_cast<T*>(p);
+    return e;
+  }
+  void release(void* p) {  // ownership moves to the caller
+    for (auto& q : ptrs)
+      if (q == p) q = nullptr;
+  }
+};
+
 int ensure_comb(eccx_ctx* ctx, int curve, const CurveOps* ops) {
   std::lock_guard<std::mutex> g(ctx->comb_mu);
   if (ctx->comb[curve]) return ECCX_OK;
   int nw = 2 * ops->info.sb;
   size_t rows = (size_t)nw * 16;
   std::vector<uint8_t> k = comb_scalars(ops);
+  DevMem mem;
   uint8_t* d_k = nullptr;
   uint32_t* d_tab = nullptr;
-  HIP_TRY(ctx, hipMalloc(&d_k, k.size()));
-  HIP_TRY(ctx, hipMalloc(&d_tab, rows * ops->info.table_words * sizeof(uint32_t)));
+  HIP_TRY(ctx, mem.alloc(&d_k, k.size()));
+  HIP_TRY(ctx, mem.alloc(&d_tab, rows * ops->info.table_words * sizeof(uint32_t)));
   HIP_TRY(ctx, hipMemcpyAsync(d_k, k.data(), k.size(), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemsetAsync(d_tab, 0, rows * ops->info.table_words * sizeof(uint32_t), ctx->stream));
   int rc = launch_var(ctx, ops, rows, d_k, nullptr, reinterpret_cast<uint8_t*>(d_tab), nullptr, nullptr,
                       K_BASE_IS_GENERATOR | K_OUT_TABLE, true, ctx->stream);
   if (rc) return rc;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  HIP_TRY(ctx, hipFree(d_k));
+  mem.release(d_tab);  // the table now belongs to the context
   ctx->comb[curve] = d_tab;
   return ECCX_OK;
 }
@@ -538,18 +560,16 @@ int eccx_comb_table(eccx_ctx* ctx, int curve, uint8_t* out) {
   size_t rows = (size_t)nw * 16, pb = 2 * (size_t)ops->info.fb;
   std::vector<uint8_t> k = comb_scalars(ops);
   std::vector<uint8_t> aff(rows * pb), fl(rows);
+  DevMem mem;
   uint8_t *d_k = nullptr, *d_o = nullptr, *d_f = nullptr;
-  HIP_TRY(ctx, hipMalloc(&d_k, k.size()));
-  HIP_TRY(ctx, hipMalloc(&d_o, aff.size()));
-  HIP_TRY(ctx, hipMalloc(&d_f, rows));
+  HIP_TRY(ctx, mem.alloc(&d_k, k.size()));
+  HIP_TRY(ctx, mem.alloc(&d_o, aff.size()));
+  HIP_TRY(ctx, mem.alloc(&d_f, rows));
   HIP_TRY(ctx, hipMemcpyAsync(d_k, k.data(), k.size(), hipMemcpyHostToDevice, ctx->stream));
   int rc = launch_var(ctx, ops, rows, d_k, nullptr, d_o, d_f, nullptr, K_BASE_IS_GENERATOR, false, ctx->stream);
   if (rc) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(aff.data(), d_o, aff.size(), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  (void)hipFree(d_k);
-  (void)hipFree(d_o);
-  (void)hipFree(d_f);
   for (int w = 0; w < nw; ++w)
     for (int d = 1; d < 16; ++d)
       std::memcpy(out + ((size_t)w * 15 + (size_t)(d - 1)) * pb, aff.data() + ((size_t)w * 16 + (size_t)d) * pb, pb);
