@@ -64,9 +64,13 @@ MEASURED_TRAFFIC = {
                     "source": "profiles/r01_x25519.json"},
 }
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# v_mad_u64_u32 issue peak measured by tools/ubench/valu_rates.hip on MI355X
-# (profiles/r01_valu_rates.jsonl): 33.0e12 lane-MACs/s with 8 waves per SIMD.
-MAC_PEAK_PER_S = 33.0e12
+# Integer-multiplier peaks measured by tools/ubench/valu_rates.hip on MI355X
+# (profiles/r01_valu_rates.jsonl, 8 waves per SIMD): the multiplier's unit of work in
+# saturated limbs is the pair v_mad_u64_u32 + v_addc_co_u32 (multiply-accumulate plus the
+# carry into the third accumulator word), 8.62 cycles per pair per SIMD = 18.2e12 lane-MACs/s
+# chip-wide; v_mad_u64_u32 alone issues at 31-33e12/s.
+MAC_PEAK_PER_S = 18.2e12
+MAD_ONLY_PEAK_PER_S = 33.0e12
 
 
 def main():
@@ -240,8 +244,10 @@ def main():
                          "alg_bytes_per_launch": alg_bytes * n,
                          "note": "integer-VALU bound path, see valu; traffic above the algorithmic bytes is "
                                  "the per-lane window table of the variable-base ladder (DESIGN.md §6)"},
-            "valu": {"bound": "v_mad_u64_u32 issue", "achieved": mac_rate / 1e12, "peak": MAC_PEAK_PER_S / 1e12,
+            "valu": {"bound": "integer multiply-accumulate issue (v_mad_u64_u32 + v_addc_co_u32 pairs)",
+                     "achieved": mac_rate / 1e12, "peak": MAC_PEAK_PER_S / 1e12,
                      "unit": "T MAC32/s", "frac": mac_rate / MAC_PEAK_PER_S,
+                     "frac_of_mad_only_peak": mac_rate / MAD_ONLY_PEAK_PER_S,
                      "macs_per_unit": field_muls * macs_per_mul},
             "cpu_baseline": cpu,
             "parity_sample_ok": parity,

@@ -13,7 +13,7 @@
 constexpr int CHAINS = 8;     // independent dependency chains per lane
 constexpr int UNROLL = 8;     // ops per chain per loop iteration
 
-enum Op { ADD_U32, ADDC_CHAIN, MAD_U64_U32, MUL_LO_U32, MUL_HI_U32, MAD_U32_U24, MUL_HI_U32_U24, FMA_F64, FMA_F32, ADD3_U32, LSHL_ADD_U64, CNDMASK, MAD_U64_U32_DEP, DOT4_U32_U8, MUL_LO_U16_PK, ALIGNBIT, ADD_LSHL };
+enum Op { ADD_U32, ADDC_CHAIN, MAD_U64_U32, MUL_LO_U32, MUL_HI_U32, MAD_U32_U24, MUL_HI_U32_U24, FMA_F64, FMA_F32, ADD3_U32, LSHL_ADD_U64, CNDMASK, MAD_U64_U32_DEP, DOT4_U32_U8, MUL_LO_U16_PK, ALIGNBIT, ADD_LSHL, MAC_PAIR, CMP_CNDMASK, DPP_SHR, BPERMUTE, SUBB_CHAIN, MAD_I64_I32, LSHR64, MOV };
 
 template <int OP>
 __global__ void __launch_bounds__(256) k_rate(uint32_t* out, int iters, uint32_t seed) {
@@ -71,6 +71,22 @@ __global__ void __launch_bounds__(256) k_rate(uint32_t* out, int iters, uint32_t
           asm volatile("v_alignbit_b32 %0, %0, %1, 7" : "+v"(a[c]) : "v"(b[c]));
         } else if constexpr (OP == ADD_LSHL) {
           asm volatile("v_add_lshl_u32 %0, %0, %1, 1" : "+v"(a[c]) : "v"(b[c]));
+        } else if constexpr (OP == MAC_PAIR) {   // the field multiplier's unit of work
+          asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(w[c]), "+v"(a[(c + 1) % CHAINS]) : "v"(a[c]), "v"(b[c]) : "vcc");
+        } else if constexpr (OP == CMP_CNDMASK) {
+          asm volatile("v_cmp_lt_u32 vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[c]) : "v"(b[c]), "v"(m) : "vcc");
+        } else if constexpr (OP == DPP_SHR) {    // cross-lane move inside a row of 16 lanes
+          asm volatile("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[c]) : "v"(b[c]));
+        } else if constexpr (OP == BPERMUTE) {   // arbitrary cross-lane gather through the LDS crossbar
+          asm volatile("ds_bpermute_b32 %0, %1, %0\n\ts_waitcnt lgkmcnt(0)" : "+v"(a[c]) : "v"(b[c]));
+        } else if constexpr (OP == SUBB_CHAIN) {
+          asm volatile("v_sub_co_u32 %0, vcc, %0, %1\n\tv_subb_co_u32 %2, vcc, %2, %1, vcc" : "+v"(a[c]), "+v"(b[c]) : "v"(m) : "vcc");
+        } else if constexpr (OP == MAD_I64_I32) {
+          asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(w[c]) : "v"(a[c]), "v"(b[c]) : "vcc");
+        } else if constexpr (OP == LSHR64) {
+          asm volatile("v_lshrrev_b64 %0, 29, %0" : "+v"(w[c]));
+        } else if constexpr (OP == MOV) {
+          asm volatile("v_mov_b32 %0, %1" : "+v"(a[c]) : "v"(b[c]));
         }
       }
     }
@@ -133,6 +149,14 @@ int main(int argc, char** argv) {
     run<MUL_HI_U32_U24>("v_mul_hi_u32_u24", 1, dout, blocks, iters);
     run<DOT4_U32_U8>("v_dot4_u32_u8", 1, dout, blocks, iters);
     run<MUL_LO_U16_PK>("v_pk_mul_lo_u16", 1, dout, blocks, iters);
+    run<MAC_PAIR>("MAC = v_mad_u64_u32 + v_addc_co_u32 (per pair)", 1, dout, blocks, iters);
+    run<CMP_CNDMASK>("v_cmp_lt_u32 + v_cndmask_b32 (per pair)", 1, dout, blocks, iters);
+    run<SUBB_CHAIN>("v_sub_co+v_subb_co pair", 2, dout, blocks, iters);
+    run<MAD_I64_I32>("v_mad_i64_i32", 1, dout, blocks, iters);
+    run<LSHR64>("v_lshrrev_b64", 1, dout, blocks, iters);
+    run<MOV>("v_mov_b32", 1, dout, blocks, iters);
+    run<DPP_SHR>("v_mov_b32_dpp row_shr:1", 1, dout, blocks, iters);
+    run<BPERMUTE>("ds_bpermute_b32 (+wait)", 1, dout, blocks, iters / 4);
     run<FMA_F32>("v_fma_f32", 1, dout, blocks, iters);
     run<FMA_F64>("v_fma_f64", 1, dout, blocks, iters);
   }
