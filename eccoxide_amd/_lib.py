@@ -11,7 +11,7 @@ import os
 from ctypes import POINTER, c_char_p, c_int, c_size_t, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libeccx.so")
+LIB_PATH = os.environ.get("ECCX_LIB_PATH") or os.path.join(_HERE, "libeccx.so")  # override: A/B builds
 
 # every symbol include/eccx.h declares, with its ctypes signature
 _u8p = c_void_p  # buffers are passed as raw addresses (bytes, bytearray, numpy, torch data_ptr)

@@ -25,6 +25,21 @@ namespace eccx {
 template <int L>
 constexpr int row5_words() { return ((5 * L + 3) / 4) * 4; }
 
+// Waves per SIMD the ladder kernel is compiled for, by limb count (8: P-256; 12: P-384,
+// BLS12-381; 17: P-521).  The MAC chain of a field multiplication is one long dependency
+// chain, so a SIMD needs several resident waves to keep its multiplier busy (measured,
+// tools/ubench/fe_bench.hip: 1470 / 1129 / 1093 / 1054 / 986 cycles per P-256 product at
+// 1 / 2 / 3 / 4 / 16 waves per SIMD); the hint trades a few spilled temporaries for residency.
+#ifndef ECCX_OCC_8
+#define ECCX_OCC_8 4
+#endif
+#ifndef ECCX_OCC_12
+#define ECCX_OCC_12 3
+#endif
+#ifndef ECCX_OCC_17
+#define ECCX_OCC_17 2
+#endif
+
 constexpr int FAST_TABLE_ROWS = 17;  // entries 1..16 of the signed 5-bit window table (+ unused row 0)
 
 template <class C>
@@ -61,7 +76,7 @@ ECCX_DEV void entry_load(JacEntry<C>& p, const uint32_t* __restrict__ row) {
 }
 
 template <class C>
-__global__ void __launch_bounds__(WG) k_scalarmul_var_fast(size_t n, const uint8_t* __restrict__ scalars,
+__global__ void __launch_bounds__(WG, (C::L <= 8 ? ECCX_OCC_8 : (C::L <= 12 ? ECCX_OCC_12 : ECCX_OCC_17))) k_scalarmul_var_fast(size_t n, const uint8_t* __restrict__ scalars,
                                                            const uint8_t* __restrict__ points,
                                                            uint32_t* __restrict__ jac_out, uint8_t* __restrict__ flags,
                                                            uint32_t* __restrict__ scratch, uint32_t opts) {

@@ -124,7 +124,7 @@ int run(const char* name, uint32_t* dout, int blocks, int iters) {
 int main() {
   uint32_t* dout;
   CK(hipMalloc(&dout, 1024 * 4 * 256 * sizeof(uint32_t)));
-  for (int blocks : {1024 * 2, 1024 * 4}) {
+  for (int blocks : {256, 512, 768, 1024, 1024 * 2, 1024 * 4}) {  // 1, 2, 3, 4, 8, 16 waves per SIMD
     run<0>("saturated 8x32 fe_mul<P256>", dout, blocks, 2000);
     run<1>("unsaturated 10x28 mul (v_mad_i64_i32)", dout, blocks, 2000);
     run<2>("unsaturated 10x28 sqr (v_mad_i64_i32)", dout, blocks, 2000);
