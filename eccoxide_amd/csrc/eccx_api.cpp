@@ -124,7 +124,7 @@ int launch_var(eccx_ctx* ctx, const CurveOps* ops, size_t n, const uint8_t* d_sc
     rc = ensure_rows(ctx, ops, n);
     if (rc) return rc;
     HIP_TRY(ctx, ops->var_fast(grid, s, n, d_scalars, d_points, ctx->jac, d_flags, ctx->scratch, kopts));
-    HIP_TRY(ctx, ops->to_affine_jac(norm_grid(ctx, n), s, n, ctx->jac, d_out, d_flags));
+    HIP_TRY(ctx, ops->to_affine_var(norm_grid(ctx, n), s, n, ctx->jac, d_out, d_flags));
     return ECCX_OK;
   }
   if (ops->info.row_words) {

@@ -47,7 +47,7 @@ hipError_t point_add_(int grid, hipStream_t s, size_t n, const uint8_t* a, const
 }
 }  // namespace
 const CurveOps& ops_BLS12_381() {
-  static const CurveOps o = {{BLS12_381::FB, BLS12_381::SB, BLS12_381::L, 2 * BLS12_381::L, row_words<BLS12_381::L>(), 0, row5_words<BLS12_381::L>(), row_words<BLS12_381::L>()}, var_, base_, var_fast_, to_affine_jac_, base_fast_, nullptr, to_affine_hom_, var_grid_, var_fast_grid_, point_add_};
+  static const CurveOps o = {{BLS12_381::FB, BLS12_381::SB, BLS12_381::L, 2 * BLS12_381::L, row_words<BLS12_381::L>(), 0, row5_words<BLS12_381::L>(), row_words<BLS12_381::L>()}, var_, base_, var_fast_, to_affine_jac_, base_fast_, nullptr, to_affine_hom_, var_grid_, var_fast_grid_, to_affine_jac_, point_add_};
   return o;
 }
 }  // namespace eccx

@@ -1,5 +1,5 @@
 // Kernel instantiations for P256 (see kernels.hpp).
-#include "kernels_fast.hpp"
+#include "kernels_u29.hpp"
 #include "launch.hpp"
 
 namespace eccx {
@@ -16,7 +16,12 @@ hipError_t base_(int grid, hipStream_t s, size_t n, const uint8_t* scalars, cons
 }
 hipError_t var_fast_(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint8_t* points, uint32_t* jac,
                      uint8_t* flags, uint32_t* scratch, uint32_t opts) {
-  hipLaunchKernelGGL(k_scalarmul_var_fast<P256>, dim3(grid), dim3(WG), 0, s, n, scalars, points, jac, flags, scratch, opts);
+  // P-256 runs the unsaturated-field ladder (kernels_u29.hpp); rows leave as plain integers
+  hipLaunchKernelGGL(k_scalarmul_var_u29<P256U>, dim3(grid), dim3(WG), 0, s, n, scalars, points, jac, flags, scratch, opts);
+  return hipGetLastError();
+}
+hipError_t to_affine_var_(int grid, hipStream_t s, size_t n, const uint32_t* jac, uint8_t* out, uint8_t* flags) {
+  hipLaunchKernelGGL((k_batch_to_affine<P256, NORM_JACOBIAN, TO_AFFINE_U, true>), dim3(grid), dim3(WG), 0, s, n, jac, out, flags);
   return hipGetLastError();
 }
 hipError_t to_affine_jac_(int grid, hipStream_t s, size_t n, const uint32_t* jac, uint8_t* out, uint8_t* flags) {
@@ -37,7 +42,7 @@ int var_grid_(int cus, size_t n) {
   return persistent_grid(occ, cus, n);
 }
 int var_fast_grid_(int cus, size_t n) {
-  static const int occ = occupancy_per_cu(k_scalarmul_var_fast<P256>);
+  static const int occ = occupancy_per_cu(k_scalarmul_var_u29<P256U>);
   return persistent_grid(occ, cus, n);
 }
 hipError_t point_add_(int grid, hipStream_t s, size_t n, const uint8_t* a, const uint8_t* a_inf, const uint8_t* b,
@@ -47,7 +52,7 @@ hipError_t point_add_(int grid, hipStream_t s, size_t n, const uint8_t* a, const
 }
 }  // namespace
 const CurveOps& ops_P256() {
-  static const CurveOps o = {{P256::FB, P256::SB, P256::L, 2 * P256::L, row_words<P256::L>(), 0, row5_words<P256::L>(), row_words<P256::L>()}, var_, base_, var_fast_, to_affine_jac_, base_fast_, nullptr, to_affine_hom_, var_grid_, var_fast_grid_, point_add_};
+  static const CurveOps o = {{P256::FB, P256::SB, P256::L, 2 * P256::L, row_words<P256::L>(), 0, urow_words<P256U>(), row_words<P256::L>()}, var_, base_, var_fast_, to_affine_jac_, base_fast_, nullptr, to_affine_hom_, var_grid_, var_fast_grid_, to_affine_var_, point_add_};
   return o;
 }
 }  // namespace eccx

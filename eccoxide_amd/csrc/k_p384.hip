@@ -47,7 +47,7 @@ hipError_t point_add_(int grid, hipStream_t s, size_t n, const uint8_t* a, const
 }
 }  // namespace
 const CurveOps& ops_P384() {
-  static const CurveOps o = {{P384::FB, P384::SB, P384::L, 2 * P384::L, row_words<P384::L>(), 0, row5_words<P384::L>(), row_words<P384::L>()}, var_, base_, var_fast_, to_affine_jac_, base_fast_, nullptr, to_affine_hom_, var_grid_, var_fast_grid_, point_add_};
+  static const CurveOps o = {{P384::FB, P384::SB, P384::L, 2 * P384::L, row_words<P384::L>(), 0, row5_words<P384::L>(), row_words<P384::L>()}, var_, base_, var_fast_, to_affine_jac_, base_fast_, nullptr, to_affine_hom_, var_grid_, var_fast_grid_, to_affine_jac_, point_add_};
   return o;
 }
 }  // namespace eccx

@@ -1,0 +1,260 @@
+// Variable-base ladder on the unsaturated field (ufe.hpp): the default kernel for P-256.
+//
+// Same contract and same algorithm as k_scalarmul_var_fast (kernels_fast.hpp): the reference's
+// &Point * &Scalar (src/curve/fiat/curve_macros.rs:321-327), Jacobian coordinates, signed
+// 5-bit windows, table d*P (d = 1..16) in a per-lane HBM slab, special cases patched per
+// lane, one doubling body and one addition body.  Only the field layer differs: 29-bit
+// limbs, single-instruction MACs, real squarings, carry-free additions; bounds are tracked
+// in the types (U<C, K, V>, see ufe.hpp), so an unsafe composition does not compile.
+// Results leave as canonical plain integers (rows X, Y, Z) for k_batch_to_affine<..., PLAIN>.
+#pragma once
+#include "kernels_fast.hpp"
+#include "ufe.hpp"
+
+namespace eccx {
+
+template <class CU>
+struct UJac {
+  U<CU, 1, 3> x, y;
+  U<CU, 2, 4> z;  // infinity <=> every limb of z is zero
+};
+
+// table entry: coordinates reduced to tight form, Z^2 and Z^3 cached
+template <class CU>
+struct UEntry {
+  U<CU, 1, 3> x, y, z;
+  U<CU, 1, 2> zz, zzz;
+};
+
+// 2P, a = -3 (dbl-2001-b with Z3 = 2YZ): 4 products + 4 squares, 3 weak reductions.
+// The comments give the (K, V) bounds the type system checks.
+template <class CU>
+ECCX_DEV void ujac_dbl(UJac<CU>& r, const UJac<CU>& p) {
+  auto delta = u_sqr(p.z);                    // (1,2)
+  auto gamma = u_sqr(p.y);                    // (1,2)
+  auto g2 = u_add(gamma, gamma);              // (2,4)
+  auto g4 = u_add(g2, g2);                    // (4,8)
+  auto b4 = u_mul(p.x, g4);                   // 4*beta             (1,2)
+  auto t1 = u_sub(p.x, delta);                // (3,7)
+  auto t2 = u_add(p.x, delta);                // (2,5)
+  auto t3 = u_mul(t1, t2);                    // (1,3)
+  auto alpha = u_reduce(u_add(u_add(t3, t3), t3));  // 3*(X-d)(X+d)   (3,9) -> (1,3)
+  auto x3a = u_sqr(alpha);                    // (1,2)
+  auto x3 = u_reduce(u_sub(u_sub(x3a, b4), b4));    // alpha^2 - 8*beta  (5,10) -> (1,3)
+  auto yz = u_mul(p.y, p.z);                  // (1,2)
+  auto g8s = u_sqr(g2);                       // 4*gamma^2          (1,2)
+  auto t = u_sub(b4, x3);                     // (3,6)
+  auto y3m = u_mul(alpha, t);                 // (1,2)
+  r.x = x3;
+  r.y = u_reduce(u_sub(u_sub(y3m, g8s), g8s));      // ... - 8*gamma^2   (5,10) -> (1,3)
+  r.z = u_add(yz, yz);                        // 2*Y*Z              (2,4)
+}
+
+// r = p + (+-e) with the generic formulas (add-1998-cmo-2, cached Z2^2, Z2^3): 11 products +
+// 3 squares, 4 weak reductions.  ey receives the (signed) entry y in tight form.
+template <class CU>
+ECCX_DEV void ujac_add_raw(UJac<CU>& r, bool& h_zero, bool& r_zero, U<CU, 1, 3>& ey, const UJac<CU>& p,
+                           const UEntry<CU>& e, bool neg) {
+  auto z1z1 = u_sqr(p.z);                     // (1,2)
+  auto u1 = u_mul(p.x, e.zz);                 // (1,2)
+  auto u2 = u_mul(e.x, z1z1);                 // (1,2)
+  auto s1 = u_mul(p.y, e.zzz);                // (1,2)
+  auto t = u_mul(p.z, z1z1);                  // (1,2)
+  U<CU, 2, 4> sy;
+  u_select(sy, neg, u_neg(e.y), u_as<2, 4>(e.y));
+  ey = u_reduce(sy);                          // (1,3)
+  auto s2 = u_mul(ey, t);                     // (1,2)
+  auto h = u_reduce(u_sub(u2, u1));           // (3,6) -> (1,3)
+  auto rr = u_reduce(u_sub(s2, s1));          // (1,3)
+  h_zero = u_is_zero_mod_p(h);
+  r_zero = u_is_zero_mod_p(rr);
+  auto hh = u_sqr(h);                         // (1,2)
+  auto hhh = u_mul(h, hh);                    // (1,2)
+  auto v = u_mul(u1, hh);                     // (1,2)
+  auto r2 = u_sqr(rr);                        // (1,2)
+  auto x3 = u_reduce(u_sub(u_sub(u_sub(r2, hhh), v), v));  // (7,14) -> (1,3)
+  auto tt = u_sub(v, x3);                     // (3,6)
+  auto y3a = u_mul(rr, tt);                   // (1,2)
+  auto s1h = u_mul(s1, hhh);                  // (1,2)
+  auto z3a = u_mul(p.z, e.z);                 // (1,2)
+  r.x = x3;
+  r.y = u_reduce(u_sub(y3a, s1h));            // (3,6) -> (1,3)
+  r.z = u_as<2, 4>(u_mul(z3a, h));            // (1,2)
+}
+
+template <class CU>
+constexpr int urow_words() { return ((5 * CU::N + 3) / 4) * 4; }
+
+template <class CU>
+ECCX_DEV void uentry_store(uint32_t* __restrict__ row, const UEntry<CU>& p) {
+  constexpr int N = CU::N;
+  constexpr int W = urow_words<CU>();
+  uint32_t w[W];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    w[i] = p.x.v[i]; w[N + i] = p.y.v[i]; w[2 * N + i] = p.z.v[i]; w[3 * N + i] = p.zz.v[i]; w[4 * N + i] = p.zzz.v[i];
+  }
+#pragma unroll
+  for (int i = 5 * N; i < W; ++i) w[i] = 0;
+  uint4* dst = reinterpret_cast<uint4*>(row);
+#pragma unroll
+  for (int i = 0; i < W / 4; ++i) dst[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+
+template <class CU>
+ECCX_DEV void uentry_load(UEntry<CU>& p, const uint32_t* __restrict__ row) {
+  constexpr int N = CU::N;
+  constexpr int W = urow_words<CU>();
+  uint32_t w[W];
+  const uint4* src = reinterpret_cast<const uint4*>(row);
+#pragma unroll
+  for (int i = 0; i < W / 4; ++i) {
+    uint4 q = src[i];
+    w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    p.x.v[i] = w[i]; p.y.v[i] = w[N + i]; p.z.v[i] = w[2 * N + i]; p.zz.v[i] = w[3 * N + i]; p.zzz.v[i] = w[4 * N + i];
+  }
+}
+
+#ifndef ECCX_OCC_U29
+#define ECCX_OCC_U29 4
+#endif
+
+template <class CU>
+__global__ void __launch_bounds__(WG, ECCX_OCC_U29) k_scalarmul_var_u29(size_t n, const uint8_t* __restrict__ scalars,
+                                                                        const uint8_t* __restrict__ points,
+                                                                        uint32_t* __restrict__ rows_out,
+                                                                        uint8_t* __restrict__ flags,
+                                                                        uint32_t* __restrict__ scratch, uint32_t opts) {
+  using CS = typename CU::Sat;
+  constexpr int L = CS::L;
+  constexpr int FB = CS::FB;
+  constexpr int SB = CS::SB;
+  constexpr int NWIN = (8 * SB + 1 + 4) / 5;
+  constexpr int W5 = urow_words<CU>();
+  constexpr int W3 = row_words<L>();
+  uint32_t* slab = scratch + ((size_t)blockIdx.x * FAST_TABLE_ROWS * WG + threadIdx.x) * (size_t)W5;
+  auto row = [&](uint32_t e) { return slab + (size_t)e * WG * W5; };
+  for (size_t base = (size_t)blockIdx.x * WG; base < n; base += (size_t)gridDim.x * WG) {
+    const size_t gid = base + threadIdx.x;
+    const bool active = gid < n;
+    const size_t idx = active ? gid : n - 1;
+
+    UJac<CU> q;
+    bool rejected = false;
+    if (opts & OPT_BASE_IS_GENERATOR) {
+#pragma unroll
+      for (int i = 0; i < CU::N; ++i) { q.x.v[i] = CU::GX[i]; q.y.v[i] = CU::GY[i]; }
+    } else {
+      Fe<L> rx, ry;
+      fe_load_be<CS>(rx, points + idx * (size_t)(2 * FB));
+      fe_load_be<CS>(ry, points + idx * (size_t)(2 * FB) + FB);
+      if (opts & OPT_VALIDATE) {  // curve equation on the saturated twin (affine.rs:103-119)
+        Fe<L> mx, my;
+        fe_to_mont<CS>(mx, rx);
+        fe_to_mont<CS>(my, ry);
+        rejected = !(fe_is_canonical<CS>(rx) && fe_is_canonical<CS>(ry) && on_curve<CS>(mx, my));
+      }
+      q.x = u_as<1, 3>(u_to_mont<CU>(rx));
+      q.y = u_as<1, 3>(u_to_mont<CU>(ry));
+    }
+    U<CU, 1, 2> one;
+#pragma unroll
+    for (int i = 0; i < CU::N; ++i) one.v[i] = CU::ONE[i];
+    q.z = u_as<2, 4>(one);
+    {
+      UEntry<CU> e1;
+      e1.x = q.x; e1.y = q.y; e1.z = u_as<1, 3>(one); e1.zz = one; e1.zzz = one;
+      uentry_store<CU>(row(1), e1);
+    }
+    const uint8_t* __restrict__ k = scalars + idx * (size_t)SB;
+
+    int b = 0;                    // table-build step: 0 -> T[2] = 2P, 1..14 -> T[b+2] = T[b+1] + P
+    int win = NWIN - 1, sub = 5;  // the top window needs no doublings
+    bool fix_pending = false, fix_lane = false;
+    for (;;) {
+      const bool building = b < 15;
+      if (!building && win < 0) break;
+      const bool do_dbl = fix_pending || (building ? (b == 0) : (sub < 5));
+      bool step_done;
+      if (do_dbl) {
+        UJac<CU> t;
+        ujac_dbl<CU>(t, q);
+        if (fix_pending) {
+          u_select(q.x, fix_lane, t.x, q.x);
+          u_select(q.y, fix_lane, t.y, q.y);
+          u_select(q.z, fix_lane, t.z, q.z);
+          fix_pending = false;
+          fix_lane = false;
+        } else {
+          q = t;
+        }
+        step_done = true;
+      } else {
+        uint32_t d = 1;
+        bool neg = false;
+        if (!building) {  // Booth digit of window `win` (see k_scalarmul_var_fast)
+          const int pos = 5 * win - 1 + 8;
+          const int bi = pos >> 3;
+          const uint32_t b0 = (bi >= 1 && bi <= SB) ? k[SB - bi] : 0u;
+          const uint32_t b1 = (bi + 1 <= SB) ? k[SB - bi - 1] : 0u;
+          const uint32_t w6 = ((b0 | (b1 << 8)) >> (pos & 7)) & 0x3fu;
+          const uint32_t s = ~((w6 >> 5) - 1u);
+          uint32_t m = (((1u << 6) - w6 - 1u) & s) | (w6 & ~s);
+          d = (m >> 1) + (m & 1u);
+          neg = (s & 1u) != 0;
+        }
+        UEntry<CU> e;
+        uentry_load<CU>(e, row(d ? d : 1));
+        const bool q_inf = u_limbs_all_zero(q.z);
+        const bool e_skip = (d == 0) || u_limbs_all_zero(e.z);
+        UJac<CU> sum;
+        U<CU, 1, 3> ey;
+        bool hz, rz;
+        ujac_add_raw<CU>(sum, hz, rz, ey, q, e, neg);
+        const bool same_x = hz && !q_inf && !e_skip;
+        fix_lane = same_x && rz;           // q == +-e with equal y: needs a doubling
+        const bool to_inf = same_x && !rz; // opposite points
+        if (to_inf) u_set_zero(sum.z);
+        // accumulator at infinity: the sum is the (signed) entry itself
+        u_select(sum.x, q_inf, e.x, sum.x);
+        u_select(sum.y, q_inf, ey, sum.y);
+        u_select(sum.z, q_inf, u_as<2, 4>(e.z), sum.z);
+        const bool keep = e_skip || fix_lane;
+        u_select(q.x, keep, q.x, sum.x);
+        u_select(q.y, keep, q.y, sum.y);
+        u_select(q.z, keep, q.z, sum.z);
+        fix_pending = __builtin_amdgcn_ballot_w64(fix_lane) != 0;
+        step_done = !fix_pending;
+      }
+      if (step_done) {
+        if (building) {
+          UEntry<CU> e;
+          e.x = q.x; e.y = q.y;
+          e.z = u_reduce(q.z);                       // tight; exact zero stays exact zero
+          e.zz = u_sqr(e.z);
+          e.zzz = u_mul(e.zz, e.z);
+          uentry_store<CU>(row(b + 2), e);
+          if (++b == 15) u_set_zero(q.z);            // accumulator starts at infinity
+        } else if (sub < 5) {
+          ++sub;
+        } else {
+          sub = 0;
+          --win;
+        }
+      }
+    }
+    if (active) {
+      Pt<CS> res;  // canonical plain integers
+      u_to_canonical<CU>(res.x, q.x);
+      u_to_canonical<CU>(res.y, q.y);
+      u_to_canonical<CU>(res.z, q.z);
+      row_store<CS>(rows_out + idx * (size_t)W3, res);
+      flags[idx] = rejected ? 2 : 0;
+    }
+  }
+}
+
+}  // namespace eccx

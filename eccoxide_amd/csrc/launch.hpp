@@ -41,6 +41,9 @@ struct CurveOps {
   // workgroups per CU from the occupancy query), so no workgroup waits for a slot
   int (*var_grid)(int cus, size_t n);
   int (*var_fast_grid)(int cus, size_t n);
+  // normalisation of the rows var_fast writes (Jacobian; plain integers for the unsaturated
+  // P-256 kernel, Montgomery limbs otherwise); may be null
+  hipError_t (*to_affine_var)(int grid, hipStream_t s, size_t n, const uint32_t* rows, uint8_t* out, uint8_t* flags);
   // batched group law a + b (or a - b) on affine inputs into un-normalised rows
   hipError_t (*point_add)(int grid, hipStream_t s, size_t n, const uint8_t* a, const uint8_t* a_inf, const uint8_t* b,
                           const uint8_t* b_inf, uint32_t* rows, uint8_t* flags, uint32_t opts);

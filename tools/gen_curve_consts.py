@@ -60,6 +60,37 @@ def emit_field(out, p, L, mersenne=0, pm19=0):
     return R
 
 
+def digits(x, bits, n):
+    return [(x >> (bits * i)) & ((1 << bits) - 1) for i in range(n)]
+
+
+def emit_unsat(out, name, sat_name, p, gx, gy, bits, n):
+    """Constants of the unsaturated representation: n limbs of `bits` bits, Montgomery with
+    R = 2^(bits*n).  BIAS is 4p written with every limb >= 2^bits - 1 (the largest tight
+    limb) so that a + BIAS - b never borrows for tight b < 3p."""
+    R = 1 << (bits * n)
+    assert p % (1 << bits) == (1 << bits) - 1, "needs p = -1 mod 2^bits (m = low limb)"
+    d = digits(4 * p, bits, n)
+    bias = [d[0] + (1 << bits)] + [d[i] + (1 << bits) - 1 for i in range(1, n - 1)] + [d[n - 1] - 1]
+    assert sum(b << (bits * i) for i, b in enumerate(bias)) == 4 * p
+    assert all(b >= (1 << bits) - 1 for b in bias[:-1]) and all(b < (1 << (bits + 1)) for b in bias)
+    assert bias[-1] >= ((3 * p) >> (bits * (n - 1))) + 1
+    out.append("struct %s {" % name)
+    out.append("  using Sat = %s;          // saturated twin (byte I/O, validation, normalisation)" % sat_name)
+    out.append("  static constexpr int N = %d;     // limbs" % n)
+    out.append("  static constexpr int B = %d;    // bits per limb" % bits)
+    out.append("  static constexpr uint32_t MASK = 0x%08xu;" % ((1 << bits) - 1))
+    out.append(arr("P", digits(p, bits, n)))
+    out.append(arr("P2", digits(2 * p, bits, n)))
+    out.append(arr("ONE", digits(R % p, bits, n)))
+    out.append(arr("R2", digits(R * R % p, bits, n)))
+    out.append(arr("BIAS", bias))
+    out.append(arr("GX", digits(gx * R % p, bits, n)))
+    out.append(arr("GY", digits(gy * R % p, bits, n)))
+    out.append("};")
+    out.append("")
+
+
 def main():
     out = ["// @generated by tools/gen_curve_consts.py -- do not edit.",
            "// Montgomery constants, 32-bit little-endian limbs, R = 2^(32*L).", ""]
@@ -77,6 +108,7 @@ def main():
         out.append(arr("GY", limbs(gy * R % p, L)))
         out.append("};")
         out.append("")
+    emit_unsat(out, "P256U", "P256", CURVES[0][1], CURVES[0][3], CURVES[0][4], 29, 9)
     L = 8
     out.append("struct ED25519 {")
     out.append("  static constexpr int L = 8;")
