@@ -110,15 +110,13 @@ ECCX_DEV void u_mul_core(uint32_t (&r)[C::N], const uint32_t (&a)[C::N], const u
     qa.flush(acc);
 #pragma unroll
     for (int i = lo; i <= (k < N ? k - 1 : N - 1); ++i) {
-      if (C::P[k - i] != 0) qm.push(acc, m[i], C::P[k - i]);
+      if (C::PP1[k - i] != 0) qm.push(acc, m[i], C::PP1[k - i]);
     }
     qm.flush(acc);
-    if (k < N) {
-      m[k] = (uint32_t)acc & C::MASK;  // -p^-1 mod 2^B = 1
-      umad1_k(acc, m[k], C::P[0]);
-    } else {
-      t[k - N] = (uint32_t)acc & C::MASK;
-    }
+    // -p^-1 mod 2^B = 1, so m[k] is the low limb itself, and m*p = m*(p+1) - m: the "- m"
+    // clears that limb (the shift drops it), m*(p+1) goes to the columns above
+    if (k < N) m[k] = (uint32_t)acc & C::MASK;
+    else t[k - N] = (uint32_t)acc & C::MASK;
     acc >>= C::B;
   }
   t[N - 1] = (uint32_t)acc;

@@ -81,6 +81,9 @@ def emit_unsat(out, name, sat_name, p, gx, gy, bits, n):
     out.append("  static constexpr int B = %d;    // bits per limb" % bits)
     out.append("  static constexpr uint32_t MASK = 0x%08xu;" % ((1 << bits) - 1))
     out.append(arr("P", digits(p, bits, n)))
+    # p + 1: adding m*p with m = the low limb of the accumulator is "drop that limb, add
+    # m*(p+1)", and p + 1 has far fewer non-zero digits (p = -1 mod 2^96 for P-256)
+    out.append(arr("PP1", digits(p + 1, bits, n)))
     out.append(arr("P2", digits(2 * p, bits, n)))
     out.append(arr("ONE", digits(R % p, bits, n)))
     out.append(arr("R2", digits(R * R % p, bits, n)))
