@@ -285,12 +285,14 @@ ECCX_DEV void fe_mul_impl(Fe<C::L>& r, const Fe<C::L>& a, const uint32_t (&b)[C:
     return;
   }
   constexpr int L = C::L;
+  // reduction digits: p + 1 when -p^-1 mod 2^32 = 1 (p = -1 mod 2^32; fewer non-zero limbs), else p
+  auto PR = [](int j) constexpr { return (C::N0 == 1u) ? C::PP1[j] : C::P[j]; };
   uint32_t m[L];
   uint32_t t[L];
   uint64_t lo = 0;
   uint32_t hi = 0;
   MacQ<BCONST> qa;  // a[i] * b[j]
-  MacQ<true> qm;    // m[i] * P[j]
+  MacQ<true> qm;    // m[i] * PR[j]
 #pragma unroll
   for (int k = 0; k < L; ++k) {
 #pragma unroll
@@ -298,12 +300,15 @@ ECCX_DEV void fe_mul_impl(Fe<C::L>& r, const Fe<C::L>& a, const uint32_t (&b)[C:
     qa.flush(lo, hi);
 #pragma unroll
     for (int i = 0; i < k; ++i) {
-      if (C::P[k - i] != 0) qm.push(lo, hi, m[i], C::P[k - i]);
+      if (PR(k - i) != 0) qm.push(lo, hi, m[i], PR(k - i));
     }
     qm.flush(lo, hi);
-    if (C::N0 == 1u) m[k] = (uint32_t)lo;
-    else m[k] = (uint32_t)lo * C::N0;
-    mac1_k(lo, hi, m[k], C::P[0]);
+    if constexpr (C::N0 == 1u) {
+      m[k] = (uint32_t)lo;  // m*p = m*(p+1) - m: "- m" clears the low word, the shift drops it
+    } else {
+      m[k] = (uint32_t)lo * C::N0;
+      mac1_k(lo, hi, m[k], C::P[0]);
+    }
     col_shift(lo, hi);
   }
 #pragma unroll
@@ -313,7 +318,7 @@ ECCX_DEV void fe_mul_impl(Fe<C::L>& r, const Fe<C::L>& a, const uint32_t (&b)[C:
     qa.flush(lo, hi);
 #pragma unroll
     for (int i = k - L + 1; i < L; ++i) {
-      if (C::P[k - i] != 0) qm.push(lo, hi, m[i], C::P[k - i]);
+      if (PR(k - i) != 0) qm.push(lo, hi, m[i], PR(k - i));
     }
     qm.flush(lo, hi);
     t[k - L] = (uint32_t)lo;

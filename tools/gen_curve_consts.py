@@ -56,6 +56,8 @@ def emit_field(out, p, L, mersenne=0, pm19=0):
     out.append(arr("R2", limbs(R * R % p, L)))
     out.append(arr("PM2", limbs(p - 2, L)))
     out.append("  static constexpr uint32_t N0 = 0x%08xu;  // -p^-1 mod 2^32" % ((-pow(p, -1, 1 << 32)) % (1 << 32)))
+    # p + 1 (used when N0 == 1: "+ m*p" is then "drop the low limb, + m*(p+1)")
+    out.append(arr("PP1", limbs((p + 1) % (1 << (32 * L)), L)))
     out.append("  static constexpr int PBITS = %d;" % p.bit_length())
     return R
 
