@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 def _var_muls(nw, dbl, inv):
-    """field mul+sqr the default (Jacobian, signed 5-bit window) variable-base path issues per
+    """field mul+sqr the saturated (Jacobian, signed 5-bit window) variable-base path issues per
     unit: window table (1 doubling + 14 additions + Z^2, Z^3 per entry), ceil((4*nw + 1)/5)
     windows of 5 doublings + 1 addition (no doublings for the top window), input conversion,
     and the batched normalisation (one Fermat inversion per 8 units)."""
@@ -37,15 +37,34 @@ def _var_muls(nw, dbl, inv):
     return (dbl + 14 * 14 + 15 * 2) + nwin * 14 + (nwin - 1) * 5 * dbl + 2 + (inv + 7) // 8 + 9
 
 
+def _sat(muls, pairs_per_mul):
+    """multiplier instructions of a saturated-limb kernel: every limb product is the pair
+    v_mad_u64_u32 + v_addc_co_u32 (fe.hpp)"""
+    return {"pair": muls * pairs_per_mul, "mad": 0}
+
+
+def _p256_var_unsat():
+    """P-256 default path (kernels_u29.hpp): 9 x 29-bit limbs, one v_mad_u64_u32 per limb
+    product; a product is 81 + 36 mads (p + 1 has 4 non-zero digits), a square 45 + 36.
+    Doubling = 4 products + 4 squares, addition = 11 + 3; 52 windows; the normalisation
+    kernel stays saturated (88 pairs per product)."""
+    mul, sqr = 81 + 36, 45 + 36
+    dbls, adds = 1 + 51 * 5, 14 + 52
+    n_mul = 4 * dbls + 11 * adds + 15 + 5      # + Z^3 per table entry + 2 to-Montgomery + 3 from-Montgomery
+    n_sqr = 4 * dbls + 3 * adds + 15           # + Z^2 per table entry
+    norm = (383 + 7) // 8 + 9 + 3
+    return {"mad": n_mul * mul + n_sqr * sqr, "pair": norm * (64 + 24)}
+
+
 WORKLOADS = {
-    # name: (curve, op, per-GPU batch, algorithmic bytes per unit, field mul+sqr per unit, MACs per field mul)
-    "p256r1_var_2^20": ("p256r1", "var", 1 << 20, 160, _var_muls(64, 8, 383), 8 * 8 + 8 * 5),
-    "ed25519_base_2^20": ("ed25519", "base", 1 << 20, 96, 64 * 7 + 2 + (380 + 7) // 8 + 7, 8 * 8 + 8),
-    "p256r1_base_2^20": ("p256r1", "base", 1 << 20, 96, 64 * 11 + (383 + 7) // 8 + 9, 8 * 8 + 8 * 5),
-    "x25519_2^20": ("ed25519", "x25519", 1 << 20, 96, 256 * 9 + (380 + 7) // 8 + 6, 8 * 8 + 8),
-    "p384r1_var_2^19": ("p384r1", "var", 1 << 19, 240, _var_muls(96, 8, 575), 12 * 12 + 12 * 10),
-    "p521r1_var_2^19": ("p521r1", "var", 1 << 19, 330, _var_muls(132, 8, 780), 17 * 17),  # Mersenne fold: no reduction MACs
-    "bls12_381_g1_var_2^20": ("bls12_381_g1", "var", 1 << 20, 224, _var_muls(64, 7, 570), 2 * 12 * 12),
+    # name: (curve, op, per-GPU batch, algorithmic bytes per unit, multiplier instructions per unit)
+    "p256r1_var_2^20": ("p256r1", "var", 1 << 20, 160, _p256_var_unsat()),
+    "ed25519_base_2^20": ("ed25519", "base", 1 << 20, 96, _sat(64 * 7 + 2 + (380 + 7) // 8 + 7, 8 * 8 + 8)),
+    "p256r1_base_2^20": ("p256r1", "base", 1 << 20, 96, _sat(64 * 11 + (383 + 7) // 8 + 9, 8 * 8 + 8 * 3)),
+    "x25519_2^20": ("ed25519", "x25519", 1 << 20, 96, _sat(256 * 9 + (380 + 7) // 8 + 6, 8 * 8 + 8)),
+    "p384r1_var_2^19": ("p384r1", "var", 1 << 19, 240, _sat(_var_muls(96, 8, 575), 12 * 12 + 12 * 10)),
+    "p521r1_var_2^19": ("p521r1", "var", 1 << 19, 330, _sat(_var_muls(132, 8, 780), 17 * 17)),  # Mersenne fold: no reduction MACs
+    "bls12_381_g1_var_2^20": ("bls12_381_g1", "var", 1 << 20, 224, _sat(_var_muls(64, 7, 570), 2 * 12 * 12)),
 }
 # HBM bytes per launch measured with rocprofv3 PMC passes (tools/profile.sh; summaries under
 # profiles/): FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for 16-byte-per-lane
@@ -53,9 +72,9 @@ WORKLOADS = {
 # read from inside this process, so the figure is the committed measurement of this very
 # workload, not a live one; null where no profile has been taken.
 MEASURED_TRAFFIC = {
-    "p256r1_var_2^20": {"bytes": 2 * (6979719147 + 113191515) + 2793436699 + 105929362,
-                        "fetch_raw": 6979719147 + 113191515, "write": 2793436699 + 105929362,
-                        "source": "profiles/r01_p256r1_var_fast.json"},
+    "p256r1_var_2^20": {"bytes": 2 * (8300380608 + 112711285) + 4666984490 + 105912394,
+                        "fetch_raw": 8300380608 + 112711285, "write": 4666984490 + 105912394,
+                        "source": "profiles/r01_p256r1_var_u29.json"},
     "ed25519_base_2^20": {"bytes": 2 * (23534773 + 112726219) + 117074368 + 105956811,
                           "fetch_raw": 23534773 + 112726219, "write": 117074368 + 105956811,
                           "source": "profiles/r01_ed25519_base.json"},
@@ -64,13 +83,14 @@ MEASURED_TRAFFIC = {
                     "source": "profiles/r01_x25519.json"},
 }
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# Integer-multiplier peaks measured by tools/ubench/valu_rates.hip on MI355X
-# (profiles/r01_valu_rates.jsonl, 8 waves per SIMD): the multiplier's unit of work in
-# saturated limbs is the pair v_mad_u64_u32 + v_addc_co_u32 (multiply-accumulate plus the
-# carry into the third accumulator word), 8.62 cycles per pair per SIMD = 18.2e12 lane-MACs/s
-# chip-wide; v_mad_u64_u32 alone issues at 31-33e12/s.
-MAC_PEAK_PER_S = 18.2e12
-MAD_ONLY_PEAK_PER_S = 33.0e12
+# Integer-multiplier issue costs measured by tools/ubench/valu_rates.hip on MI355X
+# (profiles/r01_valu_rates.jsonl): cycles one SIMD needs to issue the instruction for one
+# wave.  A lone v_mad_u64_u32 (unsaturated limbs) costs 4.8-5.03; the saturated unit of work,
+# the pair v_mad_u64_u32 + v_addc_co_u32, costs 8.62.  1024 SIMDs at 2.4 GHz.
+CYC_MAD = 4.8
+CYC_PAIR = 8.62
+SIMDS = 256 * 4
+CLOCK_HZ = 2.4e9
 
 
 def main():
@@ -113,7 +133,7 @@ def main():
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
-    curve, op, n, alg_bytes, field_muls, macs_per_mul = WORKLOADS[args.workload]
+    curve, op, n, alg_bytes, mult = WORKLOADS[args.workload]
     fb, sb = E.field_bytes(curve), E.scalar_bytes(curve)
     eng = E.Engine(dev.index)
 
@@ -216,7 +236,11 @@ def main():
         total_units = n * world * args.steps
         value = total_units / elapsed
         ach = alg_bytes * n / (kernel_ms * 1e-3) / 1e9
-        mac_rate = field_muls * macs_per_mul * n / (kernel_ms * 1e-3)
+        # time the SIMDs must spend issuing the multiplier instructions of this batch (one
+        # instruction serves the 64 units of a wave) against the kernel time
+        issue_cycles = mult["mad"] * CYC_MAD + mult["pair"] * CYC_PAIR
+        valu_frac = (n / 64) * issue_cycles / (kernel_ms * 1e-3 * SIMDS * CLOCK_HZ)
+        mul_rate = (mult["mad"] + mult["pair"]) * n / (kernel_ms * 1e-3)
         line = {
             "metric": "variable-base scalarmuls/sec (batch) per GPU + achieved HBM GB/s vs roofline"
             if op == "var" else ("X25519 scalarmuls/sec (batch) per GPU + achieved HBM GB/s vs roofline" if op == "x25519"
@@ -244,11 +268,13 @@ def main():
                          "alg_bytes_per_launch": alg_bytes * n,
                          "note": "integer-VALU bound path, see valu; traffic above the algorithmic bytes is "
                                  "the per-lane window table of the variable-base ladder (DESIGN.md §6)"},
-            "valu": {"bound": "integer multiply-accumulate issue (v_mad_u64_u32 + v_addc_co_u32 pairs)",
-                     "achieved": mac_rate / 1e12, "peak": MAC_PEAK_PER_S / 1e12,
-                     "unit": "T MAC32/s", "frac": mac_rate / MAC_PEAK_PER_S,
-                     "frac_of_mad_only_peak": mac_rate / MAD_ONLY_PEAK_PER_S,
-                     "macs_per_unit": field_muls * macs_per_mul},
+            "valu": None if args.variant != "default" else {"bound": "integer multiplier issue (v_mad_u64_u32; + v_addc_co_u32 in saturated kernels)",
+                     "achieved": mul_rate / 1e12, "unit": "T limb-products/s",
+                     "frac": valu_frac,
+                     "mads_per_unit": mult["mad"], "mad_addc_pairs_per_unit": mult["pair"],
+                     "issue_cycles_per_wave": issue_cycles,
+                     "note": "frac = share of SIMD issue time spent on multiplier instructions at the "
+                             "measured issue cost (4.8 cycles per mad, 8.62 per mad+addc pair)"},
             "cpu_baseline": cpu,
             "parity_sample_ok": parity,
         }

@@ -12,6 +12,6 @@ import json, sys
 for l in open(sys.argv[1]):
     d = json.loads(l)
     cb = d.get("cpu_baseline") or {}
-    print(d["config"]["workload"], "%.3g/s" % d["value"], "%.2f ms" % d["roofline"]["kernel_ms"], "valu %.2f" % d["valu"]["frac"],
+    print(d["config"]["workload"], "%.3g/s" % d["value"], "%.2f ms" % d["roofline"]["kernel_ms"], "valu %.2f" % ((d.get("valu") or {}).get("frac", 0)),
           "cpu %.3g/s x%d" % (cb.get("value", 0), cb.get("cores", 0)), d["parity_sample_ok"])
 PY
