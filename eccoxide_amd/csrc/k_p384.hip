@@ -1,53 +1,6 @@
-// Kernel instantiations for P384 (see kernels.hpp).
-#include "kernels_fast.hpp"
-#include "launch.hpp"
-
-namespace eccx {
-namespace {
-hipError_t var_(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint8_t* points, uint8_t* out,
-                uint8_t* flags, uint8_t* proj, uint32_t* scratch, uint32_t opts) {
-  hipLaunchKernelGGL(k_scalarmul_var<P384>, dim3(grid), dim3(WG), 0, s, n, scalars, points, out, flags, proj, scratch, opts);
-  return hipGetLastError();
-}
-hipError_t base_(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint32_t* table, uint8_t* out,
-                 uint8_t* flags, uint8_t* proj, uint32_t opts) {
-  hipLaunchKernelGGL(k_scalarmul_base<P384>, dim3(grid), dim3(WG), 0, s, n, scalars, table, out, flags, proj, opts);
-  return hipGetLastError();
-}
-hipError_t var_fast_(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint8_t* points, uint32_t* jac,
-                     uint8_t* flags, uint32_t* scratch, uint32_t opts) {
-  hipLaunchKernelGGL(k_scalarmul_var_fast<P384>, dim3(grid), dim3(WG), 0, s, n, scalars, points, jac, flags, scratch, opts);
-  return hipGetLastError();
-}
-hipError_t to_affine_jac_(int grid, hipStream_t s, size_t n, const uint32_t* jac, uint8_t* out, uint8_t* flags) {
-  hipLaunchKernelGGL((k_batch_to_affine<P384, NORM_JACOBIAN, TO_AFFINE_U>), dim3(grid), dim3(WG), 0, s, n, jac, out, flags);
-  return hipGetLastError();
-}
-hipError_t base_fast_(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint32_t* table, uint32_t* jac,
-                      uint8_t* flags) {
-  hipLaunchKernelGGL(k_scalarmul_base_fast<P384>, dim3(grid), dim3(WG), 0, s, n, scalars, table, jac, flags);
-  return hipGetLastError();
-}
-hipError_t to_affine_hom_(int grid, hipStream_t s, size_t n, const uint32_t* rows, uint8_t* out, uint8_t* flags) {
-  hipLaunchKernelGGL((k_batch_to_affine<P384, NORM_HOMOGENEOUS, TO_AFFINE_U>), dim3(grid), dim3(WG), 0, s, n, rows, out, flags);
-  return hipGetLastError();
-}
-int var_grid_(int cus, size_t n) {
-  static const int occ = occupancy_per_cu(k_scalarmul_var<P384>);
-  return persistent_grid(occ, cus, n);
-}
-int var_fast_grid_(int cus, size_t n) {
-  static const int occ = occupancy_per_cu(k_scalarmul_var_fast<P384>);
-  return persistent_grid(occ, cus, n);
-}
-hipError_t point_add_(int grid, hipStream_t s, size_t n, const uint8_t* a, const uint8_t* a_inf, const uint8_t* b,
-                      const uint8_t* b_inf, uint32_t* rows, uint8_t* flags, uint32_t opts) {
-  hipLaunchKernelGGL(k_point_add<P384>, dim3(grid), dim3(WG), 0, s, n, a, a_inf, b, b_inf, rows, flags, opts);
-  return hipGetLastError();
-}
-}  // namespace
-const CurveOps& ops_P384() {
-  static const CurveOps o = {{P384::FB, P384::SB, P384::L, 2 * P384::L, row_words<P384::L>(), 0, row5_words<P384::L>(), row_words<P384::L>()}, var_, base_, var_fast_, to_affine_jac_, base_fast_, nullptr, to_affine_hom_, var_grid_, var_fast_grid_, to_affine_jac_, point_add_};
-  return o;
-}
-}  // namespace eccx
+// Kernel instantiations for P384 (see k_weierstrass.inc).
+#define ECCX_CURVE P384
+#define ECCX_CURVE_U P384U
+#define ECCX_ROWS_PLAIN true
+#define ECCX_OPS_NAME ops_P384
+#include "k_weierstrass.inc"

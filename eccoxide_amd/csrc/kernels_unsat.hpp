@@ -15,71 +15,94 @@ namespace eccx {
 
 template <class CU>
 struct UJac {
+  // z may stay lazy (twice a product) where the field's columns have room for it
+  static constexpr int ZK = UB<CU>::KLAZY, ZV = ZK == 2 ? 4 : 3;
   U<CU, 1, 3> x, y;
-  U<CU, 2, 4> z;  // infinity <=> every limb of z is zero
+  U<CU, ZK, ZV> z;  // infinity <=> every limb of z is zero
 };
 
 // table entry: coordinates reduced to tight form, Z^2 and Z^3 cached
 template <class CU>
 struct UEntry {
-  U<CU, 1, 3> x, y, z;
-  U<CU, 1, 2> zz, zzz;
+  U<CU, 1, 3> x, y, z, zz, zzz;
 };
 
-// 2P, a = -3 (dbl-2001-b with Z3 = 2YZ): 4 products + 4 squares, 3 weak reductions.
-// The comments give the (K, V) bounds the type system checks.
+// 2P.  a = -3 (dbl-2001-b with Z3 = 2YZ): 4 products + 4 squares; a = 0 (dbl-2009-l): 2
+// products + 5 squares.  The typed operations insert a weak reduction wherever an operand's
+// bounds require one; the comments give the (K, V) bounds for P-256, where none is inserted
+// beyond the three written out.
 template <class CU>
 ECCX_DEV void ujac_dbl(UJac<CU>& r, const UJac<CU>& p) {
-  auto delta = u_sqr(p.z);                    // (1,2)
-  auto gamma = u_sqr(p.y);                    // (1,2)
-  auto g2 = u_add(gamma, gamma);              // (2,4)
-  auto g4 = u_add(g2, g2);                    // (4,8)
-  auto b4 = u_mul(p.x, g4);                   // 4*beta             (1,2)
-  auto t1 = u_sub(p.x, delta);                // (3,7)
-  auto t2 = u_add(p.x, delta);                // (2,5)
-  auto t3 = u_mul(t1, t2);                    // (1,3)
-  auto alpha = u_reduce(u_add(u_add(t3, t3), t3));  // 3*(X-d)(X+d)   (3,9) -> (1,3)
-  auto x3a = u_sqr(alpha);                    // (1,2)
-  auto x3 = u_reduce(u_sub(u_sub(x3a, b4), b4));    // alpha^2 - 8*beta  (5,10) -> (1,3)
-  auto yz = u_mul(p.y, p.z);                  // (1,2)
-  auto g8s = u_sqr(g2);                       // 4*gamma^2          (1,2)
-  auto t = u_sub(b4, x3);                     // (3,6)
-  auto y3m = u_mul(alpha, t);                 // (1,2)
-  r.x = x3;
-  r.y = u_reduce(u_sub(u_sub(y3m, g8s), g8s));      // ... - 8*gamma^2   (5,10) -> (1,3)
-  r.z = u_add(yz, yz);                        // 2*Y*Z              (2,4)
+  if constexpr (CU::Sat::A0) {
+    auto a = u_sqr(p.x);
+    auto b = u_sqr(p.y);
+    auto c = u_sqr(b);
+    auto xb = u_sqr(u_add(p.x, b));
+    auto d0 = u_sub(u_sub(xb, a), c);
+    auto d = u_reduce(u_add(d0, d0));                    // 2*((X+B)^2 - A - C)
+    auto e = u_add(u_add(a, a), a);                      // 3*A
+    auto f = u_sqr(e);
+    auto x3 = u_reduce(u_sub(u_sub(f, d), d));
+    auto c2 = u_add(c, c);
+    auto c4 = u_add(c2, c2);
+    auto c8 = u_reduce(u_add(c4, c4));
+    auto y3m = u_mul(e, u_sub(d, x3));
+    auto yz = u_mul(p.y, p.z);
+    r.x = x3;
+    r.y = u_reduce(u_sub(y3m, c8));
+    r.z = u_fit<UJac<CU>::ZK, UJac<CU>::ZV>(u_add(yz, yz));
+  } else {
+    auto delta = u_sqr(p.z);                    // (1,2)
+    auto gamma = u_sqr(p.y);                    // (1,2)
+    auto g2 = u_add(gamma, gamma);              // (2,4)
+    auto g4 = u_add(g2, g2);                    // (4,8)
+    auto b4 = u_mul(p.x, g4);                   // 4*beta             (1,2)
+    auto t1 = u_sub(p.x, delta);                // (3,7)
+    auto t2 = u_add(p.x, delta);                // (2,5)
+    auto t3 = u_mul(t1, t2);                    // (1,3)
+    auto alpha = u_reduce(u_add(u_add(t3, t3), t3));  // 3*(X-d)(X+d)   (3,9) -> (1,3)
+    auto x3a = u_sqr(alpha);                    // (1,2)
+    auto x3 = u_reduce(u_sub(u_sub(x3a, b4), b4));    // alpha^2 - 8*beta  (5,10) -> (1,3)
+    auto yz = u_mul(p.y, p.z);                  // (1,2)
+    auto g8s = u_sqr(g2);                       // 4*gamma^2          (1,2)
+    auto t = u_sub(b4, x3);                     // (3,6)
+    auto y3m = u_mul(alpha, t);                 // (1,2)
+    r.x = x3;
+    r.y = u_reduce(u_sub(u_sub(y3m, g8s), g8s));      // ... - 8*gamma^2   (5,10) -> (1,3)
+    r.z = u_fit<UJac<CU>::ZK, UJac<CU>::ZV>(u_add(yz, yz));  // 2*Y*Z      (2,4)
+  }
 }
 
 // r = p + (+-e) with the generic formulas (add-1998-cmo-2, cached Z2^2, Z2^3): 11 products +
-// 3 squares, 4 weak reductions.  ey receives the (signed) entry y in tight form.
+// 3 squares.  ey receives the (signed) entry y in tight form.
 template <class CU>
 ECCX_DEV void ujac_add_raw(UJac<CU>& r, bool& h_zero, bool& r_zero, U<CU, 1, 3>& ey, const UJac<CU>& p,
                            const UEntry<CU>& e, bool neg) {
-  auto z1z1 = u_sqr(p.z);                     // (1,2)
-  auto u1 = u_mul(p.x, e.zz);                 // (1,2)
-  auto u2 = u_mul(e.x, z1z1);                 // (1,2)
-  auto s1 = u_mul(p.y, e.zzz);                // (1,2)
-  auto t = u_mul(p.z, z1z1);                  // (1,2)
+  auto z1z1 = u_sqr(p.z);
+  auto u1 = u_mul(p.x, e.zz);
+  auto u2 = u_mul(e.x, z1z1);
+  auto s1 = u_mul(p.y, e.zzz);
+  auto t = u_mul(p.z, z1z1);
   U<CU, 2, 4> sy;
   u_select(sy, neg, u_neg(e.y), u_as<2, 4>(e.y));
-  ey = u_reduce(sy);                          // (1,3)
-  auto s2 = u_mul(ey, t);                     // (1,2)
-  auto h = u_reduce(u_sub(u2, u1));           // (3,6) -> (1,3)
-  auto rr = u_reduce(u_sub(s2, s1));          // (1,3)
+  ey = u_reduce(sy);
+  auto s2 = u_mul(ey, t);
+  auto h = u_reduce(u_sub(u2, u1));
+  auto rr = u_reduce(u_sub(s2, s1));
   h_zero = u_is_zero_mod_p(h);
   r_zero = u_is_zero_mod_p(rr);
-  auto hh = u_sqr(h);                         // (1,2)
-  auto hhh = u_mul(h, hh);                    // (1,2)
-  auto v = u_mul(u1, hh);                     // (1,2)
-  auto r2 = u_sqr(rr);                        // (1,2)
-  auto x3 = u_reduce(u_sub(u_sub(u_sub(r2, hhh), v), v));  // (7,14) -> (1,3)
-  auto tt = u_sub(v, x3);                     // (3,6)
-  auto y3a = u_mul(rr, tt);                   // (1,2)
-  auto s1h = u_mul(s1, hhh);                  // (1,2)
-  auto z3a = u_mul(p.z, e.z);                 // (1,2)
+  auto hh = u_sqr(h);
+  auto hhh = u_mul(h, hh);
+  auto v = u_mul(u1, hh);
+  auto r2 = u_sqr(rr);
+  auto x3 = u_reduce(u_sub(u_sub(u_sub(r2, hhh), v), v));
+  auto tt = u_sub(v, x3);
+  auto y3a = u_mul(rr, tt);
+  auto s1h = u_mul(s1, hhh);
+  auto z3a = u_mul(p.z, e.z);
   r.x = x3;
-  r.y = u_reduce(u_sub(y3a, s1h));            // (3,6) -> (1,3)
-  r.z = u_as<2, 4>(u_mul(z3a, h));            // (1,2)
+  r.y = u_reduce(u_sub(y3a, s1h));
+  r.z = u_fit<UJac<CU>::ZK, UJac<CU>::ZV>(u_mul(z3a, h));
 }
 
 template <class CU>
@@ -118,12 +141,15 @@ ECCX_DEV void uentry_load(UEntry<CU>& p, const uint32_t* __restrict__ row) {
   }
 }
 
-#ifndef ECCX_OCC_U29
-#define ECCX_OCC_U29 4
+// waves per SIMD the register allocator is asked to fit (measured)
+#ifndef ECCX_OCC_U14
+#define ECCX_OCC_U14 2
 #endif
+template <class CU>
+constexpr int unsat_occupancy() { return CU::N <= 9 ? 4 : (CU::N <= 14 ? ECCX_OCC_U14 : 2); }
 
 template <class CU>
-__global__ void __launch_bounds__(WG, ECCX_OCC_U29) k_scalarmul_var_u29(size_t n, const uint8_t* __restrict__ scalars,
+__global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_var_unsat(size_t n, const uint8_t* __restrict__ scalars,
                                                                         const uint8_t* __restrict__ points,
                                                                         uint32_t* __restrict__ rows_out,
                                                                         uint8_t* __restrict__ flags,
@@ -163,10 +189,10 @@ __global__ void __launch_bounds__(WG, ECCX_OCC_U29) k_scalarmul_var_u29(size_t n
     U<CU, 1, 2> one;
 #pragma unroll
     for (int i = 0; i < CU::N; ++i) one.v[i] = CU::ONE[i];
-    q.z = u_as<2, 4>(one);
+    q.z = u_as<UJac<CU>::ZK, UJac<CU>::ZV>(one);
     {
       UEntry<CU> e1;
-      e1.x = q.x; e1.y = q.y; e1.z = u_as<1, 3>(one); e1.zz = one; e1.zzz = one;
+      e1.x = q.x; e1.y = q.y; e1.z = u_as<1, 3>(one); e1.zz = e1.z; e1.zzz = e1.z;
       uentry_store<CU>(row(1), e1);
     }
     const uint8_t* __restrict__ k = scalars + idx * (size_t)SB;
@@ -221,7 +247,7 @@ __global__ void __launch_bounds__(WG, ECCX_OCC_U29) k_scalarmul_var_u29(size_t n
         // accumulator at infinity: the sum is the (signed) entry itself
         u_select(sum.x, q_inf, e.x, sum.x);
         u_select(sum.y, q_inf, ey, sum.y);
-        u_select(sum.z, q_inf, u_as<2, 4>(e.z), sum.z);
+        u_select(sum.z, q_inf, u_as<UJac<CU>::ZK, UJac<CU>::ZV>(e.z), sum.z);
         const bool keep = e_skip || fix_lane;
         u_select(q.x, keep, q.x, sum.x);
         u_select(q.y, keep, q.y, sum.y);
@@ -234,8 +260,8 @@ __global__ void __launch_bounds__(WG, ECCX_OCC_U29) k_scalarmul_var_u29(size_t n
           UEntry<CU> e;
           e.x = q.x; e.y = q.y;
           e.z = u_reduce(q.z);                       // tight; exact zero stays exact zero
-          e.zz = u_sqr(e.z);
-          e.zzz = u_mul(e.zz, e.z);
+          e.zz = u_fit<1, 3>(u_sqr(e.z));
+          e.zzz = u_fit<1, 3>(u_mul(e.zz, e.z));
           uentry_store<CU>(row(b + 2), e);
           if (++b == 15) u_set_zero(q.z);            // accumulator starts at infinity
         } else if (sub < 5) {

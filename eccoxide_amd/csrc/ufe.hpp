@@ -1,30 +1,36 @@
 // Unsaturated field arithmetic for the fast kernels: N limbs of B < 32 bits in 32-bit
-// registers, Montgomery with R = 2^(B*N).
+// registers.
 //
 // Why: on gfx950 a carry instruction costs as much as a multiply (profiles/r01_valu_rates.jsonl),
 // so the saturated multiplier (fe.hpp) spends half its issue slots on v_addc_co_u32.  With
-// 29-bit limbs a column of the product -- at most 9 limb products plus 9 reduction products,
-// each below 2^58 -- fits a 64-bit accumulator with room to spare: the unit of work is ONE
-// v_mad_u64_u32, squares really cost half the cross products, additions are 9 independent
-// v_add_u32 and there is no conditional subtraction.  Measured (tools/ubench/fe_bench29.hip,
-// 4 waves per SIMD): 773 cycles per P-256 product and 631 per square against 1046 for the
-// saturated form.
+// 28/29-bit limbs a whole column of the product fits a 64-bit accumulator: the unit of work
+// is ONE v_mad_u64_u32, squares really cost half the cross products, additions are N
+// independent v_add_u32 and there is no conditional subtraction.
+//
+// Three kinds of field (C::KIND), all reproducing the reference's values modulo p only
+// (canonical bytes are produced at the very end, u_to_canonical):
+//   0  Montgomery, R = 2^(B*N), p = -1 mod 2^B: the Montgomery factor m is the low limb of
+//      the accumulator itself and "+ m*p" becomes "drop that limb, + m*(p+1)"; p + 1 has few
+//      non-zero digits for the NIST primes (P-256: 4 of 9)     (src/curve/fiat/p256_64.rs, p384_64.rs)
+//   1  Montgomery, general p (BLS12-381): m = acc * (-p^-1) mod 2^B   (src/curve/fiat/bls12_381_*.rs)
+//   2  p = 2^k - 1 (P-521), plain representation: the wrapped half of the product is
+//      accumulated into the same columns with weight 2^(B*N - k)          (src/curve/fiat/p521_64.rs)
 //
 // The price is bookkeeping, done at compile time.  Every value carries two bounds in its
 // type, U<C, K, V>:
-//   K  every limb is < K * 2^B          (K = 1: "tight", the unique radix-2^B digits;
-//                                         the top limb holds whatever is left above)
+//   K  every limb is < K * 2^B (+ a few units)   (K = 1: "tight"; after u_reduce the digits
+//                                                are the unique radix-2^B digits)
 //   V  the integer value is < V * p
-// and each operation states what it needs and what it returns (static_assert):
-//   mul / sqr   need 9*K1*K2*2^(2B) + 9*2^(2B) + carry < 2^64  <=>  K1*K2 <= 6 (sqr: K <= 2),
-//               and V1*V2 <= 64; return tight, V = 2 (V1*V2 <= 32) or 3
-//   add         K1+K2, V1+V2, no instructions beyond N adds
-//   sub         a + BIAS - b with BIAS = 4p spread so no limb borrows; needs b tight, Vb <= 3;
+// Each operation knows what it needs (UB<C>) and, where an operand is too loose, reduces it
+// first (if constexpr) -- so a formula written once is valid for every field, and an unsafe
+// composition cannot be expressed:
+//   mul / sqr   N*K1*K2*2^(2B) (+ N*2^(2B) reduction products) + carry < 2^64; the Montgomery
+//               result is < (V1*V2/(R/p) + 1) * p, required < 3p; tight output
+//   add         K1+K2 <= KMAX (limbs below 2^32), V1+V2
+//   sub         a + BIAS - b with BIAS = 4p spread so no limb borrows; b tight and < 3p;
 //               returns K1+2, V1+4
-//   reduce      one signed carry chain that also subtracts q*p, q ~ value >> 256: needs K <= 7,
-//               V <= 31; returns tight, V = 3
-// Values of the reference (fiat-crypto Montgomery, src/curve/fiat/p256_64.rs) are reproduced
-// modulo p only; canonical bytes are produced at the very end (u_to_canonical).
+//   reduce      one signed carry chain that also takes off q*p, q ~ value / p estimated from the
+//               top limbs: returns exact tight digits of a value < 3p
 #pragma once
 #include "fe.hpp"
 
@@ -32,11 +38,34 @@ namespace eccx {
 
 #include "umad_chunks.inc"
 
+enum : int { UK_MONT_PP1 = 0, UK_MONT = 1, UK_MERSENNE = 2 };
+
 template <class C, int K, int V>
 struct U {
-  static_assert(K >= 1 && K <= 7, "limb bound out of range (limbs must stay below 2^32)");
-  static_assert(V >= 1 && V <= 31, "value bound out of range (must stay below 2^(B*N))");
+  static_assert(K >= 1 && K < (1 << (32 - C::B)), "limb bound out of range (limbs must stay below 2^32)");
+  static_assert(V >= 1 && V <= 4096, "value bound out of range");
   uint32_t v[C::N];
+};
+
+// what the multiplier columns and the 32-bit limbs can take
+template <class C>
+struct UB {
+  static constexpr bool MONT = C::KIND != UK_MERSENNE;
+  static constexpr int KMAX = (1 << (32 - C::B)) - 1;
+  static constexpr uint64_t COL = (uint64_t)1 << (2 * C::B);  // one product of tight limbs
+  // largest K1*K2 a product may have: Montgomery columns hold N products + N reduction
+  // products; the Mersenne columns hold N direct products + N - 1 doubled wrapped ones
+  static constexpr int KKMAX = MONT ? (int)(~(uint64_t)0 / ((uint64_t)C::N * COL)) - 1
+                                    : (int)(~(uint64_t)0 / ((uint64_t)(2 * C::N - 1) * COL));
+  static_assert(KKMAX >= 1, "limbs too wide for this many columns");
+  static constexpr bool kk_ok(int k1, int k2) { return k1 * k2 <= KKMAX; }
+  // squares also shift the operand left by one (two for the wrapped cross terms)
+  static constexpr int KSQ_SHIFT = MONT ? 1 : 2;
+  static constexpr bool ksq_ok(int k) { return k * k <= KKMAX && (k << KSQ_SHIFT) <= KMAX + 1; }
+  // bound of a product of values below v1*p and v2*p
+  static constexpr int vout(int v1, int v2) { return MONT ? (int)(((uint32_t)(v1 * v2) + C::RP - 1) / C::RP) + 1 : 3; }
+  // laziest limb bound a value may have and still be squared / multiplied by a tight value
+  static constexpr int KLAZY = ksq_ok(2) ? 2 : 1;
 };
 
 // queue of pending single-instruction MACs (see MacQ in fe.hpp)
@@ -83,11 +112,15 @@ struct UMacQ {
   }
 };
 
-// Montgomery product / square core on raw limb arrays; bounds are checked by the typed wrappers.
+// ---- product cores on raw limb arrays; bounds are checked by the typed wrappers -----------
+
+// Montgomery product / square (kinds 0 and 1): product scanning, one 64-bit column at a time
 template <class C, bool SQR, bool BCONST>
-ECCX_DEV void u_mul_core(uint32_t (&r)[C::N], const uint32_t (&a)[C::N], const uint32_t (&b)[C::N]) {
+ECCX_DEV void u_mul_core_mont(uint32_t (&r)[C::N], const uint32_t (&a)[C::N], const uint32_t (&b)[C::N]) {
   constexpr int N = C::N;
-  static_assert(N <= 9, "column queue holds 9 products");
+  constexpr bool PP1 = C::KIND == UK_MONT_PP1;
+  // digits added per Montgomery factor: p + 1 (whose digit 0 is zero) or p
+  auto PR = [](int j) constexpr { return PP1 ? C::PP1[j] : C::P[j]; };
   uint32_t m[N], t[N], a2[N];
   if constexpr (SQR) {
 #pragma unroll
@@ -110,13 +143,21 @@ ECCX_DEV void u_mul_core(uint32_t (&r)[C::N], const uint32_t (&a)[C::N], const u
     qa.flush(acc);
 #pragma unroll
     for (int i = lo; i <= (k < N ? k - 1 : N - 1); ++i) {
-      if (C::PP1[k - i] != 0) qm.push(acc, m[i], C::PP1[k - i]);
+      if (PR(k - i) != 0) qm.push(acc, m[i], PR(k - i));
     }
     qm.flush(acc);
-    // -p^-1 mod 2^B = 1, so m[k] is the low limb itself, and m*p = m*(p+1) - m: the "- m"
-    // clears that limb (the shift drops it), m*(p+1) goes to the columns above
-    if (k < N) m[k] = (uint32_t)acc & C::MASK;
-    else t[k - N] = (uint32_t)acc & C::MASK;
+    if (k < N) {
+      if constexpr (PP1) {
+        // -p^-1 mod 2^B = 1, so m[k] is the low limb itself, and m*p = m*(p+1) - m: the "- m"
+        // clears that limb (the shift drops it), m*(p+1) goes to the columns above
+        m[k] = (uint32_t)acc & C::MASK;
+      } else {
+        m[k] = ((uint32_t)acc * C::N0B) & C::MASK;
+        umad1_k(acc, m[k], C::P[0]);
+      }
+    } else {
+      t[k - N] = (uint32_t)acc & C::MASK;
+    }
     acc >>= C::B;
   }
   t[N - 1] = (uint32_t)acc;
@@ -124,76 +165,92 @@ ECCX_DEV void u_mul_core(uint32_t (&r)[C::N], const uint32_t (&a)[C::N], const u
   for (int i = 0; i < N; ++i) r[i] = t[i];
 }
 
-template <class C, int K1, int V1, int K2, int V2>
-ECCX_DEV U<C, 1, (V1 * V2 <= 32 ? 2 : 3)> u_mul(const U<C, K1, V1>& a, const U<C, K2, V2>& b) {
-  static_assert(K1 * K2 <= 6, "product column would overflow 64 bits");
-  static_assert(V1 * V2 <= 64, "Montgomery output would not stay below 3p");
-  U<C, 1, (V1 * V2 <= 32 ? 2 : 3)> r;
-  u_mul_core<C, false, false>(r.v, a.v, b.v);
-  return r;
-}
-
-template <class C, int K1, int V1>
-ECCX_DEV U<C, 1, (V1 * V1 <= 32 ? 2 : 3)> u_sqr(const U<C, K1, V1>& a) {
-  static_assert(K1 <= 2, "square column would overflow 64 bits");
-  static_assert(V1 * V1 <= 64, "Montgomery output would not stay below 3p");
-  U<C, 1, (V1 * V1 <= 32 ? 2 : 3)> r;
-  u_mul_core<C, true, false>(r.v, a.v, a.v);
-  return r;
-}
-
-// multiply by a compile-time constant given as tight digits (R^2, 1)
-template <class C, int K1, int V1>
-ECCX_DEV U<C, 1, 2> u_mul_k(const U<C, K1, V1>& a, const uint32_t (&k)[C::N]) {
-  static_assert(K1 <= 6 && V1 <= 31, "bounds");
-  U<C, 1, 2> r;
-  u_mul_core<C, false, true>(r.v, a.v, k);
-  return r;
-}
-
-template <class C, int K1, int V1, int K2, int V2>
-ECCX_DEV U<C, K1 + K2, V1 + V2> u_add(const U<C, K1, V1>& a, const U<C, K2, V2>& b) {
-  U<C, K1 + K2, V1 + V2> r;
+// Mersenne product / square (kind 2), p = 2^k - 1 with B*N - k = S: the product's upper half
+// has weight 2^(B*N) = 2^S (mod p), so a_i * b_j with i + j >= N is accumulated into column
+// i + j - N times 2^S.  Inputs tight; output tight (digit 1 may exceed 2^B by the last carry).
+template <class C, bool SQR, bool BCONST>
+ECCX_DEV void u_mul_core_mers(uint32_t (&r)[C::N], const uint32_t (&a)[C::N], const uint32_t (&b)[C::N]) {
+  constexpr int N = C::N;
+  constexpr int S = C::B * N - C::PBITS;
+  static_assert(S >= 1 && S <= 2, "wrap factor must keep shifted limbs below 2^32");
+  uint32_t t[N], bw[N], a2[N];
 #pragma unroll
-  for (int i = 0; i < C::N; ++i) r.v[i] = a.v[i] + b.v[i];
-  return r;
-}
-
-// a - b (+ 4p): b must be tight and below 3p so that BIAS - b has no negative limb
-template <class C, int K1, int V1, int V2>
-ECCX_DEV U<C, K1 + 2, V1 + 4> u_sub(const U<C, K1, V1>& a, const U<C, 1, V2>& b) {
-  static_assert(V2 <= 3, "subtrahend too large for the 4p bias");
-  U<C, K1 + 2, V1 + 4> r;
+  for (int i = 0; i < N; ++i) {
+    if constexpr (SQR) {
+      a2[i] = a[i] << 1;
+      bw[i] = a[i] << (S + 1);
+    } else {
+      a2[i] = 0;
+      bw[i] = b[i] << S;
+    }
+  }
+  uint64_t acc = 0;
+  UMacQ<BCONST && !SQR> qa;
+  UMacQ<false> qw;
 #pragma unroll
-  for (int i = 0; i < C::N; ++i) r.v[i] = a.v[i] + (C::BIAS[i] - b.v[i]);
-  return r;
-}
-
-template <class C, int V2>
-ECCX_DEV U<C, 2, 4> u_neg(const U<C, 1, V2>& b) {
-  static_assert(V2 <= 3, "operand too large for the 4p bias");
-  U<C, 2, 4> r;
+  for (int k = 0; k < N; ++k) {
+    if constexpr (SQR) {
+      // direct terms i + j = k, wrapped terms i + j = k + N; i < j doubled, i == j once
 #pragma unroll
-  for (int i = 0; i < C::N; ++i) r.v[i] = C::BIAS[i] - b.v[i];
-  return r;
+      for (int i = 0; 2 * i < k; ++i) qa.push(acc, a[i], a2[k - i]);
+      if ((k & 1) == 0) qa.push(acc, a[k / 2], a[k / 2]);
+      qa.flush(acc);
+#pragma unroll
+      for (int i = k + 1; 2 * i < k + N; ++i) qw.push(acc, a[i], bw[k + N - i]);
+      if (((k + N) & 1) == 0) {
+        if constexpr (S == 1) qw.push(acc, a[(k + N) / 2], a2[(k + N) / 2]);
+        else qw.push(acc, a2[(k + N) / 2], a2[(k + N) / 2]);
+      }
+      qw.flush(acc);
+    } else {
+#pragma unroll
+      for (int i = 0; i <= k; ++i) qa.push(acc, a[i], b[k - i]);
+      qa.flush(acc);
+#pragma unroll
+      for (int i = k + 1; i < N; ++i) qw.push(acc, a[i], bw[k + N - i]);
+      qw.flush(acc);
+    }
+    t[k] = (uint32_t)acc & C::MASK;
+    acc >>= C::B;
+  }
+  // what is left has weight 2^(B*N) = 2^S again
+  acc = (acc << S) + t[0];
+  t[0] = (uint32_t)acc & C::MASK;
+  t[1] += (uint32_t)(acc >> C::B);
+#pragma unroll
+  for (int i = 0; i < N; ++i) r[i] = t[i];
 }
 
-// Weak reduction: propagate carries and take off q*p with q = (value >> 256) estimated from
-// the two top limbs (it may be one too small), in one signed chain.  Result: tight digits of
-// a value in [0, 2^256 + p) -- below 3p.
+template <class C, bool SQR, bool BCONST>
+ECCX_DEV void u_mul_core(uint32_t (&r)[C::N], const uint32_t (&a)[C::N], const uint32_t (&b)[C::N]) {
+  if constexpr (C::KIND == UK_MERSENNE) u_mul_core_mers<C, SQR, BCONST>(r, a, b);
+  else u_mul_core_mont<C, SQR, BCONST>(r, a, b);
+}
+
+// ---- weak reduction -----------------------------------------------------------------------
+// Propagate carries and take off q*p, q ~ value / p estimated from the two top limbs (never
+// too large, at most one or two too small), in one signed chain.  Result: the exact radix-2^B
+// digits of a value in [0, 3p).
 template <class C, int K1, int V1>
 ECCX_DEV U<C, 1, 3> u_reduce(const U<C, K1, V1>& a) {
   constexpr int N = C::N;
-  constexpr int TOPSHIFT = 256 - C::B * (N - 1);  // bit 256 inside the top limb (24 for 9 x 29)
-  static_assert(C::B * (N - 1) < 256 && C::B * N > 256, "layout assumed by the quotient estimate");
-  const uint32_t q = (a.v[N - 1] + (a.v[N - 2] >> C::B)) >> TOPSHIFT;
+  const uint32_t top = a.v[N - 1] + (a.v[N - 2] >> C::B);
+  uint32_t q;
+  if constexpr (C::QMUL != 0) q = __umulhi(top, C::QMUL);
+  else q = top >> C::TOPSHIFT;
   const int32_t nq = -(int32_t)q;
   U<C, 1, 3> r;
   int64_t acc = 0;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     acc += (int64_t)a.v[i];
-    if (C::P[i] != 0) acc += (int64_t)nq * (int64_t)(int32_t)C::P[i];
+    if constexpr (C::KIND == UK_MERSENNE) {
+      // q * p = q * 2^PBITS - q
+      if (i == 0) acc += (int64_t)q;
+      if (i == N - 1) acc -= (int64_t)q << C::TOPSHIFT;
+    } else {
+      if (C::P[i] != 0) acc += (int64_t)nq * (int64_t)(int32_t)C::P[i];
+    }
     if (i < N - 1) {
       r.v[i] = (uint32_t)acc & C::MASK;
       acc >>= C::B;  // arithmetic shift: a negative partial sum borrows from the next limb
@@ -212,6 +269,90 @@ ECCX_DEV U<C, K2, V2> u_as(const U<C, K1, V1>& a) {
 #pragma unroll
   for (int i = 0; i < C::N; ++i) r.v[i] = a.v[i];
   return r;
+}
+
+// bring a value into the bounds (K2, V2) >= (1, 3): as is if it fits, reduced otherwise
+template <int K2, int V2, class C, int K1, int V1>
+ECCX_DEV U<C, K2, V2> u_fit(const U<C, K1, V1>& a) {
+  static_assert(K2 >= 1 && V2 >= 3, "target must admit a reduced value");
+  if constexpr (K1 <= K2 && V1 <= V2) return u_as<K2, V2>(a);
+  else return u_as<K2, V2>(u_reduce(a));
+}
+
+// ---- typed operations (reduce an operand first where its bounds require it) ----------------
+template <class C, int K1, int V1, int K2, int V2>
+ECCX_DEV auto u_mul(const U<C, K1, V1>& a, const U<C, K2, V2>& b) {
+  if constexpr (!UB<C>::kk_ok(K1, K2) || (UB<C>::vout(V1, V2) > 3)) {
+    if constexpr (K1 > K2 || (K1 == K2 && V1 >= V2)) return u_mul(u_reduce(a), b);
+    else return u_mul(a, u_reduce(b));
+  } else {
+    U<C, 1, UB<C>::vout(V1, V2)> r;
+    u_mul_core<C, false, false>(r.v, a.v, b.v);
+    return r;
+  }
+}
+
+template <class C, int K1, int V1>
+ECCX_DEV auto u_sqr(const U<C, K1, V1>& a) {
+  if constexpr (!UB<C>::ksq_ok(K1) || (UB<C>::vout(V1, V1) > 3)) {
+    return u_sqr(u_reduce(a));
+  } else {
+    U<C, 1, UB<C>::vout(V1, V1)> r;
+    u_mul_core<C, true, false>(r.v, a.v, a.v);
+    return r;
+  }
+}
+
+// multiply by a compile-time constant given as tight digits of a value below p (R^2, 1)
+template <class C, int K1, int V1>
+ECCX_DEV auto u_mul_k(const U<C, K1, V1>& a, const uint32_t (&k)[C::N]) {
+  if constexpr (!UB<C>::kk_ok(K1, 1) || (UB<C>::vout(V1, 1) > 3)) {
+    return u_mul_k(u_reduce(a), k);
+  } else {
+    U<C, 1, UB<C>::vout(V1, 1)> r;
+    u_mul_core<C, false, true>(r.v, a.v, k);
+    return r;
+  }
+}
+
+template <class C, int K1, int V1, int K2, int V2>
+ECCX_DEV auto u_add(const U<C, K1, V1>& a, const U<C, K2, V2>& b) {
+  if constexpr (K1 + K2 > UB<C>::KMAX) {
+    if constexpr (K1 >= K2) return u_add(u_reduce(a), b);
+    else return u_add(a, u_reduce(b));
+  } else {
+    U<C, K1 + K2, V1 + V2> r;
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) r.v[i] = a.v[i] + b.v[i];
+    return r;
+  }
+}
+
+// a - b (+ 4p): b must be tight and below 3p so that BIAS - b has no negative limb
+template <class C, int K1, int V1, int K2, int V2>
+ECCX_DEV auto u_sub(const U<C, K1, V1>& a, const U<C, K2, V2>& b) {
+  if constexpr (K2 != 1 || V2 > 3) {
+    return u_sub(a, u_reduce(b));
+  } else if constexpr (K1 + 2 > UB<C>::KMAX) {
+    return u_sub(u_reduce(a), b);
+  } else {
+    U<C, K1 + 2, V1 + 4> r;
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) r.v[i] = a.v[i] + (C::BIAS[i] - b.v[i]);
+    return r;
+  }
+}
+
+template <class C, int K2, int V2>
+ECCX_DEV auto u_neg(const U<C, K2, V2>& b) {
+  if constexpr (K2 != 1 || V2 > 3) {
+    return u_neg(u_reduce(b));
+  } else {
+    U<C, 2, 4> r;
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) r.v[i] = C::BIAS[i] - b.v[i];
+    return r;
+  }
 }
 
 template <class C, int K, int V>
@@ -234,12 +375,12 @@ ECCX_DEV void u_set_zero(U<C, K, V>& a) {
   for (int i = 0; i < C::N; ++i) a.v[i] = 0;
 }
 
-// value == 0 (mod p) for a TIGHT value below 3p: its digits equal those of 0, p or 2p.
-// k*p = -k (mod 2^B), so the low limb filters all but 3 in 2^B values before the full compare.
+// value == 0 (mod p) for the OUTPUT OF u_reduce (exact digits, below 3p): its digits equal
+// those of 0, p or 2p; the low limb filters nearly everything before the full compare.
 template <class C>
 ECCX_DEV bool u_is_zero_mod_p(const U<C, 1, 3>& a) {
   const uint32_t l0 = a.v[0];
-  if (!(l0 == 0 || l0 >= C::MASK - 1)) return false;
+  if (!(l0 == 0 || l0 == C::P[0] || l0 == C::P2[0])) return false;
   uint32_t d0 = 0, d1 = 0, d2 = 0;
 #pragma unroll
   for (int i = 0; i < C::N; ++i) {
@@ -250,24 +391,26 @@ ECCX_DEV bool u_is_zero_mod_p(const U<C, 1, 3>& a) {
   return d0 == 0 || d1 == 0 || d2 == 0;
 }
 
-// ---- conversions with the saturated representation (plain integers, 8 x 32) ------------
-// plain saturated integer (< 2^256) -> tight digits (value unchanged)
+// ---- conversions with the saturated representation (plain integers, L x 32) --------------
+// plain saturated integer -> tight digits (value unchanged; below 2p for canonical input)
 template <class C>
 ECCX_DEV U<C, 1, 2> u_from_sat(const Fe<C::Sat::L>& s) {
-  static_assert(C::Sat::L * 32 == 256, "conversion written for 256-bit fields");
+  constexpr int L = C::Sat::L;
+  static_assert(C::B * C::N >= C::PBITS, "digits must cover the field");
   U<C, 1, 2> r;
 #pragma unroll
   for (int i = 0; i < C::N; ++i) {
     const int bit = C::B * i;
     const int w = bit >> 5, sh = bit & 31;
-    uint64_t lo = s.v[w];
-    if (w + 1 < C::Sat::L) lo |= (uint64_t)s.v[w + 1] << 32;
+    uint64_t lo = 0;
+    if (w < L) lo = s.v[w];
+    if (w + 1 < L) lo |= (uint64_t)s.v[w + 1] << 32;
     r.v[i] = (uint32_t)(lo >> sh) & C::MASK;
   }
   return r;
 }
 
-// tight digits of a value < 2^256 -> saturated limbs
+// exact tight digits of a value below 2^(32L) -> saturated limbs
 template <class C, int V>
 ECCX_DEV void u_to_sat(Fe<C::Sat::L>& s, const U<C, 1, V>& a) {
 #pragma unroll
@@ -286,22 +429,29 @@ ECCX_DEV void u_to_sat(Fe<C::Sat::L>& s, const U<C, 1, V>& a) {
   }
 }
 
-// plain canonical integer (saturated) -> Montgomery form, tight
+// plain canonical integer (saturated) -> the field's working form (Montgomery or plain), tight
 template <class C>
 ECCX_DEV U<C, 1, 2> u_to_mont(const Fe<C::Sat::L>& plain) {
-  return u_mul_k<C>(u_from_sat<C>(plain), C::R2);
+  if constexpr (UB<C>::MONT) return u_as<1, 2>(u_mul_k<C>(u_from_sat<C>(plain), C::R2));
+  else return u_from_sat<C>(plain);
 }
 
-// Montgomery form -> canonical plain integer in saturated limbs (the unique residue < p)
+// working form -> canonical plain integer in saturated limbs (the unique residue < p)
 template <class C, int K, int V>
 ECCX_DEV void u_to_canonical(Fe<C::Sat::L>& out, const U<C, K, V>& a) {
-  uint32_t one[C::N];
-#pragma unroll
-  for (int i = 0; i < C::N; ++i) one[i] = (i == 0) ? 1u : 0u;
-  // (a + m p) / R with a < 31p << R: the result is in [0, p]
-  U<C, 1, 2> r = u_mul_k<C>(a, one);
   Fe<C::Sat::L> s;
-  u_to_sat<C>(s, r);
+  if constexpr (UB<C>::MONT) {
+    uint32_t one[C::N];
+#pragma unroll
+    for (int i = 0; i < C::N; ++i) one[i] = (i == 0) ? 1u : 0u;
+    // (a + m p) / R with a < 3p << R: the result is in [0, p]
+    auto r = u_mul_k<C>(u_reduce(a), one);
+    u_to_sat<C>(s, r);
+  } else {
+    // twice: the second pass sees exact digits, so its quotient is exact and the result <= p + 2
+    auto r = u_reduce(u_reduce(a));
+    u_to_sat<C>(s, r);
+  }
   uint32_t t[C::Sat::L];
 #pragma unroll
   for (int i = 0; i < C::Sat::L; ++i) t[i] = s.v[i];

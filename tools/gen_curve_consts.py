@@ -66,22 +66,44 @@ def digits(x, bits, n):
     return [(x >> (bits * i)) & ((1 << bits) - 1) for i in range(n)]
 
 
-def emit_unsat(out, name, sat_name, p, gx, gy, bits, n):
-    """Constants of the unsaturated representation: n limbs of `bits` bits, Montgomery with
-    R = 2^(bits*n).  BIAS is 4p written with every limb >= 2^bits - 1 (the largest tight
-    limb) so that a + BIAS - b never borrows for tight b < 3p."""
-    R = 1 << (bits * n)
-    assert p % (1 << bits) == (1 << bits) - 1, "needs p = -1 mod 2^bits (m = low limb)"
+def emit_unsat(out, name, sat_name, p, gx, gy, bits, n, kind):
+    """Constants of the unsaturated representation: n limbs of `bits` bits in 32-bit registers.
+    kind 0: Montgomery, R = 2^(bits*n), p = -1 mod 2^bits (reduce with the digits of p + 1)
+    kind 1: Montgomery, general p (m = acc * N0B mod 2^bits)
+    kind 2: p = 2^k - 1, plain representation, 2^(bits*n) = 2^(bits*n - k) mod p folded into the product
+    BIAS is 4p written with every limb >= 2^bits - 1 (the largest tight limb) so that
+    a + BIAS - b never borrows for tight b < 3p."""
+    mont = kind in (0, 1)
+    R = (1 << (bits * n)) if mont else 1
+    pbits = p.bit_length()
+    if kind == 0:
+        assert p % (1 << bits) == (1 << bits) - 1, "needs p = -1 mod 2^bits (m = low limb)"
     d = digits(4 * p, bits, n)
+    assert sum(x << (bits * i) for i, x in enumerate(d)) == 4 * p or 4 * p >= 1 << (bits * n)
+    d[n - 1] = (4 * p) >> (bits * (n - 1))  # the top digit takes whatever is left
     bias = [d[0] + (1 << bits)] + [d[i] + (1 << bits) - 1 for i in range(1, n - 1)] + [d[n - 1] - 1]
     assert sum(b << (bits * i) for i, b in enumerate(bias)) == 4 * p
     assert all(b >= (1 << bits) - 1 for b in bias[:-1]) and all(b < (1 << (bits + 1)) for b in bias)
-    assert bias[-1] >= ((3 * p) >> (bits * (n - 1))) + 1
+    # a tight value below 3p (Montgomery kinds) or below 2^(bits*n) (plain kinds) has a top digit <= bias top
+    top_tight = ((3 * p) >> (bits * (n - 1))) if mont else (1 << bits) - 1
+    assert bias[-1] >= top_tight, (name, hex(bias[-1]), hex(top_tight))
+    topshift = pbits - bits * (n - 1)
+    assert 0 < topshift < bits
+    ptop = p >> (bits * (n - 1))
+    # quotient estimate for the weak reduction: q = top >> TOPSHIFT when the top digit of p is
+    # all ones below bit TOPSHIFT (Solinas / Mersenne), else q = mulhi(top, QMUL) (never too large)
+    qmul = 0 if ptop == (1 << topshift) - 1 else (1 << 32) // (ptop + 1)
     out.append("struct %s {" % name)
     out.append("  using Sat = %s;          // saturated twin (byte I/O, validation, normalisation)" % sat_name)
     out.append("  static constexpr int N = %d;     // limbs" % n)
     out.append("  static constexpr int B = %d;    // bits per limb" % bits)
+    out.append("  static constexpr int KIND = %d;  // 0 Montgomery p = -1 mod 2^B, 1 Montgomery general, 2 Mersenne (plain)" % kind)
+    out.append("  static constexpr int PBITS = %d;" % pbits)
+    out.append("  static constexpr int TOPSHIFT = %d;  // bit PBITS inside the top limb" % topshift)
+    out.append("  static constexpr uint32_t QMUL = 0x%08xu;  // 0: quotient estimate is a shift" % qmul)
+    out.append("  static constexpr uint32_t RP = %du;  // floor(R / p), capped" % min(R // p, 1 << 20))
     out.append("  static constexpr uint32_t MASK = 0x%08xu;" % ((1 << bits) - 1))
+    out.append("  static constexpr uint32_t N0B = 0x%08xu;  // -p^-1 mod 2^B" % ((-pow(p, -1, 1 << bits)) % (1 << bits)))
     out.append(arr("P", digits(p, bits, n)))
     # p + 1: adding m*p with m = the low limb of the accumulator is "drop that limb, add
     # m*(p+1)", and p + 1 has far fewer non-zero digits (p = -1 mod 2^96 for P-256)
@@ -113,7 +135,10 @@ def main():
         out.append(arr("GY", limbs(gy * R % p, L)))
         out.append("};")
         out.append("")
-    emit_unsat(out, "P256U", "P256", CURVES[0][1], CURVES[0][3], CURVES[0][4], 29, 9)
+    emit_unsat(out, "P256U", "P256", CURVES[0][1], CURVES[0][3], CURVES[0][4], 29, 9, 0)
+    emit_unsat(out, "P384U", "P384", CURVES[1][1], CURVES[1][3], CURVES[1][4], 28, 14, 0)
+    emit_unsat(out, "P521U", "P521", CURVES[2][1], CURVES[2][3], CURVES[2][4], 29, 18, 2)
+    emit_unsat(out, "BLS12_381U", "BLS12_381", CURVES[3][1], CURVES[3][3], CURVES[3][4], 28, 14, 1)
     L = 8
     out.append("struct ED25519 {")
     out.append("  static constexpr int L = 8;")
