@@ -43,28 +43,33 @@ def _sat(muls, pairs_per_mul):
     return {"pair": muls * pairs_per_mul, "mad": 0}
 
 
-def _p256_var_unsat():
-    """P-256 default path (kernels_u29.hpp): 9 x 29-bit limbs, one v_mad_u64_u32 per limb
-    product; a product is 81 + 36 mads (p + 1 has 4 non-zero digits), a square 45 + 36.
-    Doubling = 4 products + 4 squares, addition = 11 + 3; 52 windows; the normalisation
-    kernel stays saturated (88 pairs per product)."""
-    mul, sqr = 81 + 36, 45 + 36
-    dbls, adds = 1 + 51 * 5, 14 + 52
-    n_mul = 4 * dbls + 11 * adds + 15 + 5      # + Z^3 per table entry + 2 to-Montgomery + 3 from-Montgomery
-    n_sqr = 4 * dbls + 3 * adds + 15           # + Z^2 per table entry
-    norm = (383 + 7) // 8 + 9 + 3
-    return {"mad": n_mul * mul + n_sqr * sqr, "pair": norm * (64 + 24)}
+def _var_unsat(n, nz, sb, a0, inv, sat_pairs, mont=True):
+    """default variable-base path (kernels_unsat.hpp): n limbs of 28/29 bits, one
+    v_mad_u64_u32 per limb product.  A product is n*n + n*nz mads (nz = non-zero reduction
+    digits per Montgomery factor: those of p + 1 for the NIST primes, all n for BLS12-381,
+    none for the Mersenne prime whose wrapped half shares the columns), a square n(n+1)/2 +
+    n*nz.  Doubling = 4 products + 4 squares (a = -3) or 2 + 5 (a = 0), addition = 11 + 3;
+    ceil((8*sb + 1)/5) signed windows; the normalisation kernel stays saturated."""
+    mul, sqr = n * n + n * nz, n * (n + 1) // 2 + n * nz
+    nwin = (8 * sb + 1 + 4) // 5
+    dbls, adds = 1 + (nwin - 1) * 5, 14 + nwin
+    dm, ds = (2, 5) if a0 else (4, 4)
+    conv = 5 if mont else 0                      # 2 to-Montgomery + 3 from-Montgomery products
+    n_mul = dm * dbls + 11 * adds + 15 + conv    # + Z^3 per table entry
+    n_sqr = ds * dbls + 3 * adds + 15            # + Z^2 per table entry
+    norm = (inv + 7) // 8 + 9 + (3 if mont else 0)
+    return {"mad": n_mul * mul + n_sqr * sqr, "pair": norm * sat_pairs}
 
 
 WORKLOADS = {
     # name: (curve, op, per-GPU batch, algorithmic bytes per unit, multiplier instructions per unit)
-    "p256r1_var_2^20": ("p256r1", "var", 1 << 20, 160, _p256_var_unsat()),
+    "p256r1_var_2^20": ("p256r1", "var", 1 << 20, 160, _var_unsat(9, 4, 32, 0, 383, 8 * 8 + 8 * 3)),
     "ed25519_base_2^20": ("ed25519", "base", 1 << 20, 96, _sat(64 * 7 + 2 + (380 + 7) // 8 + 7, 8 * 8 + 8)),
     "p256r1_base_2^20": ("p256r1", "base", 1 << 20, 96, _sat(64 * 11 + (383 + 7) // 8 + 9, 8 * 8 + 8 * 3)),
     "x25519_2^20": ("ed25519", "x25519", 1 << 20, 96, _sat(256 * 9 + (380 + 7) // 8 + 6, 8 * 8 + 8)),
-    "p384r1_var_2^19": ("p384r1", "var", 1 << 19, 240, _sat(_var_muls(96, 8, 575), 12 * 12 + 12 * 10)),
-    "p521r1_var_2^19": ("p521r1", "var", 1 << 19, 330, _sat(_var_muls(132, 8, 780), 17 * 17)),  # Mersenne fold: no reduction MACs
-    "bls12_381_g1_var_2^20": ("bls12_381_g1", "var", 1 << 20, 224, _sat(_var_muls(64, 7, 570), 2 * 12 * 12)),
+    "p384r1_var_2^19": ("p384r1", "var", 1 << 19, 240, _var_unsat(14, 12, 48, 0, 575, 12 * 12 + 12 * 10)),
+    "p521r1_var_2^19": ("p521r1", "var", 1 << 19, 330, _var_unsat(18, 0, 66, 0, 780, 17 * 17, mont=False)),
+    "bls12_381_g1_var_2^20": ("bls12_381_g1", "var", 1 << 20, 224, _var_unsat(14, 14, 32, 1, 570, 2 * 12 * 12)),
 }
 # HBM bytes per launch measured with rocprofv3 PMC passes (tools/profile.sh; summaries under
 # profiles/): FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for 16-byte-per-lane

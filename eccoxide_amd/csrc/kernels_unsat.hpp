@@ -12,6 +12,9 @@
 #include "ufe.hpp"
 
 namespace eccx {
+#ifndef ECCX_EXP_ROW
+#define ECCX_EXP_ROW(d) (d)
+#endif
 
 template <class CU>
 struct UJac {
@@ -50,6 +53,25 @@ ECCX_DEV void ujac_dbl(UJac<CU>& r, const UJac<CU>& p) {
     auto yz = u_mul(p.y, p.z);
     r.x = x3;
     r.y = u_reduce(u_sub(y3m, c8));
+    r.z = u_fit<UJac<CU>::ZK, UJac<CU>::ZV>(u_add(yz, yz));
+  } else if constexpr (UB<CU>::KKMAX == 1) {
+    // fields whose multiplier wants tight operands (P-521): 4 products + 4 squares, and the
+    // multiples of beta and gamma^2 are formed after the product so that each is reduced once
+    auto delta = u_sqr(p.z);
+    auto gamma = u_sqr(p.y);
+    auto beta = u_mul(p.x, gamma);
+    auto t2 = u_add(p.x, delta);
+    auto alpha = u_mul(u_sub(p.x, delta), u_add(u_add(t2, t2), t2));  // 3*(X-d)(X+d)
+    auto b2 = u_add(beta, beta);
+    auto b4 = u_reduce(u_add(b2, b2));
+    auto x3 = u_reduce(u_sub(u_sub(u_sqr(alpha), b4), b4));
+    auto gg = u_sqr(gamma);
+    auto gg2 = u_add(gg, gg);
+    auto gg4 = u_reduce(u_add(gg2, gg2));
+    auto y3m = u_mul(alpha, u_sub(b4, x3));
+    auto yz = u_mul(p.y, p.z);  // not (Y+Z)^2 - g - d: Z = 0 must give the all-zero limbs back
+    r.x = x3;
+    r.y = u_reduce(u_sub(u_sub(y3m, gg4), gg4));
     r.z = u_fit<UJac<CU>::ZK, UJac<CU>::ZV>(u_add(yz, yz));
   } else {
     auto delta = u_sqr(p.z);                    // (1,2)
@@ -233,7 +255,7 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_var_uns
           neg = (s & 1u) != 0;
         }
         UEntry<CU> e;
-        uentry_load<CU>(e, row(d ? d : 1));
+        uentry_load<CU>(e, row(ECCX_EXP_ROW(d ? d : 1)));
         const bool q_inf = u_limbs_all_zero(q.z);
         const bool e_skip = (d == 0) || u_limbs_all_zero(e.z);
         UJac<CU> sum;

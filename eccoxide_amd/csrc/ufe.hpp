@@ -238,24 +238,31 @@ ECCX_DEV U<C, 1, 3> u_reduce(const U<C, K1, V1>& a) {
   uint32_t q;
   if constexpr (C::QMUL != 0) q = __umulhi(top, C::QMUL);
   else q = top >> C::TOPSHIFT;
-  const int32_t nq = -(int32_t)q;
   U<C, 1, 3> r;
-  int64_t acc = 0;
+  if constexpr (C::KIND == UK_MERSENNE) {
+    // q * p = q * 2^PBITS - q: q enters at the bottom, q << TOPSHIFT leaves at the top; every
+    // partial sum is non-negative and below 2^32, so the chain is plain 32-bit arithmetic
+    uint32_t c = q;
 #pragma unroll
-  for (int i = 0; i < N; ++i) {
-    acc += (int64_t)a.v[i];
-    if constexpr (C::KIND == UK_MERSENNE) {
-      // q * p = q * 2^PBITS - q
-      if (i == 0) acc += (int64_t)q;
-      if (i == N - 1) acc -= (int64_t)q << C::TOPSHIFT;
-    } else {
-      if (C::P[i] != 0) acc += (int64_t)nq * (int64_t)(int32_t)C::P[i];
+    for (int i = 0; i < N - 1; ++i) {
+      const uint32_t t = a.v[i] + c;
+      r.v[i] = t & C::MASK;
+      c = t >> C::B;
     }
-    if (i < N - 1) {
-      r.v[i] = (uint32_t)acc & C::MASK;
-      acc >>= C::B;  // arithmetic shift: a negative partial sum borrows from the next limb
-    } else {
-      r.v[i] = (uint32_t)acc;
+    r.v[N - 1] = a.v[N - 1] + c - (q << C::TOPSHIFT);
+  } else {
+    const int32_t nq = -(int32_t)q;
+    int64_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      acc += (int64_t)a.v[i];
+      if (C::P[i] != 0) acc += (int64_t)nq * (int64_t)(int32_t)C::P[i];
+      if (i < N - 1) {
+        r.v[i] = (uint32_t)acc & C::MASK;
+        acc >>= C::B;  // arithmetic shift: a negative partial sum borrows from the next limb
+      } else {
+        r.v[i] = (uint32_t)acc;
+      }
     }
   }
   return r;
