@@ -1,0 +1,171 @@
+"""GPU stress test of the unsaturated field layer (eccoxide_amd/csrc/ufe.hpp).
+
+The scalar-multiplication parity tests only ever feed the field layer the limb values real
+ladders produce.  The layer's safety argument is about bounds, though: every operation is
+typed with the largest limbs (K) and value (V) it may receive, and the 64-bit product columns
+and 32-bit limbs must not overflow at those extremes.  This test drives single operations
+through tests/hip/libfieldcheck.so with the worst inputs the types admit (all limbs at
+K*2^B - 1, value just under V*p, digits of 0 / p / 2p) plus random ones, and checks every
+result against Python integers: congruence modulo p, limb bound and value bound of the
+output type.
+"""
+import ctypes
+import os
+import random
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "tests", "hip", "libfieldcheck.so")
+
+P = {
+    0: 2**256 - 2**224 + 2**192 + 2**96 - 1,
+    1: 2**384 - 2**128 - 2**96 + 2**32 - 1,
+    2: 2**521 - 1,
+    3: 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB,
+}
+NAMES = {0: "p256r1", 1: "p384r1", 2: "p521r1", 3: "bls12_381_g1"}
+OP_MUL_TIGHT, OP_MUL_LAZY, OP_SQR_LAZY, OP_SUB_CHAIN, OP_REDUCE_MAX, OP_CANONICAL, OP_MUL_AUTO, OP_ADD_AUTO = range(8)
+
+
+class FieldCheck:
+    def __init__(self):
+        import torch  # noqa: F401  (one HIP runtime in the process, as eccoxide_amd._lib does)
+
+        self.lib = ctypes.CDLL(LIB)
+        self.lib.fieldcheck_info.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+        self.lib.fieldcheck_run.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_size_t]
+
+    def info(self, curve):
+        arr = (ctypes.c_int * 8)()
+        assert self.lib.fieldcheck_info(curve, arr) == 0
+        return dict(zip(["N", "B", "KMAX", "KKMAX", "KA", "KB", "KS", "L"], list(arr)))
+
+    def run(self, curve, op, a, b):
+        a = np.ascontiguousarray(a, dtype=np.uint32)
+        b = np.ascontiguousarray(b, dtype=np.uint32)
+        out = np.zeros_like(a)
+        rc = self.lib.fieldcheck_run(curve, op, a.ctypes.data, b.ctypes.data, out.ctypes.data, a.shape[0])
+        assert rc == 0, f"fieldcheck_run failed: hip error {rc}"
+        return out
+
+
+@pytest.fixture(scope="module")
+def fc():
+    if not os.path.exists(LIB):
+        pytest.fail("tests/hip/libfieldcheck.so missing: run __graft_entry__.build()")
+    return FieldCheck()
+
+
+def value(limbs, B):
+    return sum(int(x) << (B * i) for i, x in enumerate(limbs))
+
+
+def gen(rng, inf, p, K, V, count):
+    """rows of N limbs, each limb < K*2^B, value < V*p: extremes first, then random"""
+    N, B = inf["N"], inf["B"]
+    wtop = B * (N - 1)
+    top_cap = min(K * (1 << B) - 1, (V * p >> wtop) - K - 1)
+    assert top_cap > 0
+    lim = K * (1 << B) - 1
+    rows = []
+
+    def row(lo, top):
+        r = [min(x, lim) for x in lo] + [min(top, top_cap)]
+        assert value(r, B) < V * p
+        return r
+
+    rows.append(row([lim] * (N - 1), top_cap))            # everything at the bound
+    rows.append(row([0] * (N - 1), 0))                     # zero
+    rows.append(row([lim] * (N - 1), 0))
+    rows.append(row([0] * (N - 1), top_cap))
+    rows.append(row([(1 << B) - 1] * (N - 1), top_cap))    # tight all-ones
+    for m in (1, 2):                                       # digits of p and 2p (zero mod p)
+        d = [(m * p >> (B * i)) & ((1 << B) - 1) for i in range(N - 1)] + [m * p >> wtop]
+        if d[-1] <= top_cap:
+            rows.append(d)
+    rows.append(row([lim if i % 2 else 0 for i in range(N - 1)], top_cap))
+    rows.append(row([0 if i % 2 else lim for i in range(N - 1)], top_cap))
+    while len(rows) < count:
+        style = rng.random()
+        if style < 0.3:   # mostly-max limbs with a few random ones
+            lo = [lim if rng.random() < 0.8 else rng.randrange(lim + 1) for _ in range(N - 1)]
+        else:
+            lo = [rng.randrange(lim + 1) for _ in range(N - 1)]
+        rows.append(row(lo, rng.randrange(top_cap + 1)))
+    return rows
+
+
+def mont_factor(curve, inf):
+    """what one product divides by: R for the Montgomery fields, 1 for the plain one"""
+    return 1 if curve == 2 else 1 << (inf["B"] * inf["N"])
+
+
+def check_out(out_row, inf, p, want_mod, k_out=1, v_out=3, slack=1 << 8, exact_digits=False):
+    B, N = inf["B"], inf["N"]
+    v = value(out_row, B)
+    assert v % p == want_mod % p, "wrong residue"
+    assert v < v_out * p, f"value bound exceeded: {v / p:.3f} p"
+    for i, x in enumerate(out_row[:-1]):
+        bound = k_out * (1 << B) + (0 if exact_digits else slack)
+        assert int(x) < bound, f"limb {i} = {int(x):#x} exceeds its bound"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve", [0, 1, 2, 3], ids=lambda c: NAMES[c])
+def test_products_at_the_operand_bounds(fc, curve):
+    rng = random.Random(100 + curve)
+    inf, p = fc.info(curve), P[curve]
+    rinv = pow(mont_factor(curve, inf), -1, p)
+    n = 512
+    # (operation, bounds of a, bounds of b)
+    cases = [(OP_MUL_TIGHT, (1, 3), (1, 3)),
+             (OP_MUL_LAZY, (inf["KA"], 7), (inf["KB"], 5)),
+             (OP_SQR_LAZY, (inf["KS"], 4), None),
+             (OP_MUL_AUTO, (inf["KMAX"], 64), (inf["KMAX"], 64))]
+    for op, (ka, va), bb in cases:
+        a = gen(rng, inf, p, ka, va, n)
+        b = gen(rng, inf, p, bb[0], bb[1], n) if bb else a
+        rng.shuffle(b) if bb else None
+        out = fc.run(curve, op, a, b)
+        for ra, rb, ro in zip(a, b, out):
+            va_, vb_ = value(ra, inf["B"]), value(rb, inf["B"])
+            check_out(ro, inf, p, va_ * vb_ * rinv)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve", [0, 1, 2, 3], ids=lambda c: NAMES[c])
+def test_sums_differences_and_reductions(fc, curve):
+    rng = random.Random(200 + curve)
+    inf, p = fc.info(curve), P[curve]
+    n = 512
+    a = gen(rng, inf, p, 1, 3, n)
+    b = gen(rng, inf, p, 1, 3, n)
+    rng.shuffle(b)
+    out = fc.run(curve, OP_SUB_CHAIN, a, b)
+    for ra, rb, ro in zip(a, b, out):
+        check_out(ro, inf, p, value(ra, inf["B"]) - 3 * value(rb, inf["B"]), exact_digits=True)
+    a = gen(rng, inf, p, inf["KMAX"], 64, n)
+    out = fc.run(curve, OP_REDUCE_MAX, a, a)
+    for ra, ro in zip(a, out):
+        check_out(ro, inf, p, value(ra, inf["B"]), exact_digits=True)
+    b = gen(rng, inf, p, inf["KMAX"], 64, n)
+    rng.shuffle(b)
+    out = fc.run(curve, OP_ADD_AUTO, a, b)
+    for ra, rb, ro in zip(a, b, out):
+        check_out(ro, inf, p, 2 * (value(ra, inf["B"]) + value(rb, inf["B"])), exact_digits=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve", [0, 1, 2, 3], ids=lambda c: NAMES[c])
+def test_canonical_output_is_the_unique_residue(fc, curve):
+    rng = random.Random(300 + curve)
+    inf, p = fc.info(curve), P[curve]
+    rinv = pow(mont_factor(curve, inf), -1, p)
+    a = gen(rng, inf, p, inf["KMAX"], 64, 512)
+    out = fc.run(curve, OP_CANONICAL, a, a)
+    for ra, ro in zip(a, out):
+        got = sum(int(x) << (32 * i) for i, x in enumerate(ro[: inf["L"]]))
+        assert got == value(ra, inf["B"]) * rinv % p
