@@ -46,6 +46,7 @@ struct eccx_ctx {
   int cus = 0;
   hipStream_t stream = nullptr;
   uint32_t* comb[NCURVES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  uint32_t* comb_u[NCURVES] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // unsaturated-field copies
   std::mutex comb_mu;
   uint32_t* scratch = nullptr;
   size_t scratch_words = 0;
@@ -193,9 +194,30 @@ int ensure_comb(eccx_ctx* ctx, int curve, const CurveOps* ops) {
   int rc = launch_var(ctx, ops, rows, d_k, nullptr, reinterpret_cast<uint8_t*>(d_tab), nullptr, nullptr,
                       K_BASE_IS_GENERATOR | K_OUT_TABLE, true, ctx->stream);
   if (rc) return rc;
+  // 8-bit-window table of the unsaturated fixed-base kernel: entry (w, d) = d * 256^w * G,
+  // computed by the engine's own variable-base path
+  uint32_t* d_utab = nullptr;
+  if (ops->base_unsat) {
+    const size_t urows = (size_t)ops->info.sb * 256, pb = 2 * (size_t)ops->info.fb;
+    std::vector<uint8_t> uk(urows * ops->info.sb, 0);
+    for (int w = 0; w < ops->info.sb; ++w)
+      for (int d = 0; d < 256; ++d) uk[((size_t)w * 256 + d) * ops->info.sb + (ops->info.sb - 1 - w)] = (uint8_t)d;
+    uint8_t *d_uk = nullptr, *d_aff = nullptr, *d_fl = nullptr;
+    HIP_TRY(ctx, mem.alloc(&d_uk, uk.size()));
+    HIP_TRY(ctx, mem.alloc(&d_aff, urows * pb));
+    HIP_TRY(ctx, mem.alloc(&d_fl, urows));
+    HIP_TRY(ctx, mem.alloc(&d_utab, urows * (size_t)ops->utable_words * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMemcpyAsync(d_uk, uk.data(), uk.size(), hipMemcpyHostToDevice, ctx->stream));
+    rc = launch_var(ctx, ops, urows, d_uk, nullptr, d_aff, d_fl, nullptr, K_BASE_IS_GENERATOR, false, ctx->stream);
+    if (rc) return rc;
+    HIP_TRY(ctx, ops->comb_convert(ctx->stream, urows, d_aff, d_utab));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // uk lives on the host until the copy is done
+  }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  mem.release(d_tab);  // the table now belongs to the context
+  mem.release(d_tab);  // the tables now belong to the context
+  if (d_utab) mem.release(d_utab);
   ctx->comb[curve] = d_tab;
+  ctx->comb_u[curve] = d_utab;
   return ECCX_OK;
 }
 
@@ -312,6 +334,8 @@ void eccx_shutdown(eccx_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (auto& t : ctx->comb)
     if (t) (void)hipFree(t);
+  for (auto& t : ctx->comb_u)
+    if (t) (void)hipFree(t);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->jac) (void)hipFree(ctx->jac);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -359,6 +383,16 @@ int eccx_scalarmul_base_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_sc
   hipStream_t s = static_cast<hipStream_t>(stream);  // NULL = HIP's default stream
   size_t need = (n + eccx::LAUNCH_WG - 1) / eccx::LAUNCH_WG;
   int grid = (int)std::max<size_t>(1, std::min(need, (size_t)ctx->cus * 8));
+  if (!d_proj && !(opts & ECCX_MIRROR_REFERENCE) && ops->base_unsat && ctx->comb_u[curve]) {
+    rc = ensure_rows(ctx, ops, n);
+    if (rc) return rc;
+    const int ugrid = ops->var_fast_grid ? std::max(grid, ops->var_fast_grid(ctx->cus, n)) : grid;
+    HIP_TRY(ctx, ops->base_unsat(ugrid, s, n, static_cast<const uint8_t*>(d_scalars), ctx->comb_u[curve], ctx->jac,
+                                 static_cast<uint8_t*>(d_flags)));
+    HIP_TRY(ctx, ops->to_affine_var(norm_grid(ctx, n), s, n, ctx->jac, static_cast<uint8_t*>(d_out),
+                                    static_cast<uint8_t*>(d_flags)));
+    return ECCX_OK;
+  }
   if (!d_proj && !(opts & ECCX_MIRROR_REFERENCE) && ops->base_fast) {
     rc = ensure_rows(ctx, ops, n);
     if (rc) return rc;

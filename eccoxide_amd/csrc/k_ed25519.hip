@@ -51,7 +51,7 @@ hipError_t launch_x25519_to_u(int grid, hipStream_t s, size_t n, const uint32_t*
   return hipGetLastError();
 }
 const CurveOps& ops_ED25519() {
-  static const CurveOps o = {{ED25519::FB, ED25519::SB, ED25519::L, 4 * ED25519::L, 0, 1, 0, row_words<ED25519::L>()}, var_, base_, nullptr, nullptr, nullptr, base_lds_, to_affine_hom_, var_grid_, nullptr, nullptr, point_add_};
+  static const CurveOps o = {{ED25519::FB, ED25519::SB, ED25519::L, 4 * ED25519::L, 0, 1, 0, row_words<ED25519::L>()}, var_, base_, nullptr, nullptr, nullptr, base_lds_, to_affine_hom_, var_grid_, nullptr, nullptr, point_add_, 0, nullptr, nullptr};
   return o;
 }
 }  // namespace eccx

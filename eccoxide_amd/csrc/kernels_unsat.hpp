@@ -305,4 +305,126 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_var_uns
   }
 }
 
+// ---- fixed base (comb) on the unsaturated field -------------------------------------------
+
+// r = p + (x2, y2, 1): madd with the affine table entry, 8 products + 3 squares
+template <class CU>
+ECCX_DEV void ujac_madd_raw(UJac<CU>& r, bool& h_zero, bool& r_zero, const UJac<CU>& p, const U<CU, 1, 2>& x2,
+                            const U<CU, 1, 2>& y2) {
+  auto z1z1 = u_sqr(p.z);
+  auto u2 = u_mul(x2, z1z1);
+  auto t = u_mul(p.z, z1z1);
+  auto s2 = u_mul(y2, t);
+  auto h = u_reduce(u_sub(u2, p.x));
+  auto rr = u_reduce(u_sub(s2, p.y));
+  h_zero = u_is_zero_mod_p(h);
+  r_zero = u_is_zero_mod_p(rr);
+  auto hh = u_sqr(h);
+  auto hhh = u_mul(h, hh);
+  auto v = u_mul(p.x, hh);
+  auto r2 = u_sqr(rr);
+  auto x3 = u_reduce(u_sub(u_sub(u_sub(r2, hhh), v), v));
+  auto y3a = u_mul(rr, u_sub(v, x3));
+  auto y1h = u_mul(p.y, hhh);
+  r.x = x3;
+  r.y = u_reduce(u_sub(y3a, y1h));
+  r.z = u_fit<UJac<CU>::ZK, UJac<CU>::ZV>(u_mul(p.z, h));
+}
+
+template <class CU>
+constexpr int utable_words() { return ((2 * CU::N + 3) / 4) * 4; }
+
+// affine points as canonical big-endian bytes (x | y, what the engine's own variable-base path
+// produces for the table scalars) -> table entries in the unsaturated field's form
+template <class CU>
+__global__ void k_affine_to_utable(size_t entries, const uint8_t* __restrict__ affine, uint32_t* __restrict__ utable) {
+  using CS = typename CU::Sat;
+  constexpr int L = CS::L;
+  constexpr int FB = CS::FB;
+  constexpr int UW = utable_words<CU>();
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= entries) return;
+  Fe<L> px, py;
+  fe_load_be<CS>(px, affine + i * (size_t)(2 * FB));
+  fe_load_be<CS>(py, affine + i * (size_t)(2 * FB) + FB);
+  const auto ux = u_to_mont<CU>(px);
+  const auto uy = u_to_mont<CU>(py);
+  uint32_t* o = utable + i * UW;
+#pragma unroll
+  for (int k = 0; k < UW; ++k) o[k] = k < CU::N ? ux.v[k] : (k < 2 * CU::N ? uy.v[k - CU::N] : 0u);
+}
+
+// Fixed-base comb: the reference's mul_base (src/curve/fiat/curve_macros.rs) adds one table
+// entry per 4-bit window with no doublings; the result k*G does not depend on the window width,
+// so this kernel uses 8-bit windows -- entry (w, d) = d * 256^w * G, half the additions -- from
+// a table the engine builds for itself (SB x 256 entries, L2 resident).  Jacobian mixed
+// additions; same special cases as k_scalarmul_base_fast.
+template <class CU>
+__global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_base_unsat(size_t n, const uint8_t* __restrict__ scalars,
+                                                                                  const uint32_t* __restrict__ table,
+                                                                                  uint32_t* __restrict__ rows_out,
+                                                                                  uint8_t* __restrict__ flags) {
+  using CS = typename CU::Sat;
+  constexpr int L = CS::L;
+  constexpr int SB = CS::SB;
+  constexpr int NW = SB;  // one window per scalar byte
+  constexpr int W3 = row_words<L>();
+  constexpr int UW = utable_words<CU>();
+  for (size_t base = (size_t)blockIdx.x * WG; base < n; base += (size_t)gridDim.x * WG) {
+    const size_t gid = base + threadIdx.x;
+    const bool active = gid < n;
+    const size_t idx = active ? gid : n - 1;
+    const uint8_t* __restrict__ k = scalars + idx * (size_t)SB;
+    U<CU, 1, 2> one;
+#pragma unroll
+    for (int i = 0; i < CU::N; ++i) one.v[i] = CU::ONE[i];
+    UJac<CU> q;
+    q.x = u_as<1, 3>(one);
+    q.y = u_as<1, 3>(one);
+    u_set_zero(q.z);  // infinity
+    for (int w = 0; w < NW; ++w) {
+      const uint32_t d = k[SB - 1 - w];
+      const uint4* __restrict__ e = reinterpret_cast<const uint4*>(table + ((size_t)w * 256 + (d ? d : 1)) * UW);
+      uint32_t ew[UW];
+#pragma unroll
+      for (int i = 0; i < UW / 4; ++i) {
+        const uint4 v = e[i];
+        ew[4 * i] = v.x; ew[4 * i + 1] = v.y; ew[4 * i + 2] = v.z; ew[4 * i + 3] = v.w;
+      }
+      U<CU, 1, 2> x2, y2;
+#pragma unroll
+      for (int i = 0; i < CU::N; ++i) { x2.v[i] = ew[i]; y2.v[i] = ew[CU::N + i]; }
+      const bool q_inf = u_limbs_all_zero(q.z);
+      const bool e_skip = (d == 0);
+      UJac<CU> sum;
+      bool hz, rz;
+      ujac_madd_raw<CU>(sum, hz, rz, q, x2, y2);
+      const bool same_x = hz && !q_inf && !e_skip;
+      const bool need_dbl = same_x && rz;
+      if (same_x && !rz) u_set_zero(sum.z);  // q == -entry
+      u_select(sum.x, q_inf, u_as<1, 3>(x2), sum.x);
+      u_select(sum.y, q_inf, u_as<1, 3>(y2), sum.y);
+      u_select(sum.z, q_inf, u_as<UJac<CU>::ZK, UJac<CU>::ZV>(one), sum.z);
+      if (__builtin_amdgcn_ballot_w64(need_dbl) != 0) {  // q == entry: rare, wave-uniform branch
+        UJac<CU> t;
+        ujac_dbl<CU>(t, q);
+        u_select(sum.x, need_dbl, t.x, sum.x);
+        u_select(sum.y, need_dbl, t.y, sum.y);
+        u_select(sum.z, need_dbl, t.z, sum.z);
+      }
+      u_select(q.x, e_skip, q.x, sum.x);
+      u_select(q.y, e_skip, q.y, sum.y);
+      u_select(q.z, e_skip, q.z, sum.z);
+    }
+    if (active) {
+      Pt<CS> res;  // canonical plain integers
+      u_to_canonical<CU>(res.x, q.x);
+      u_to_canonical<CU>(res.y, q.y);
+      u_to_canonical<CU>(res.z, q.z);
+      row_store<CS>(rows_out + idx * (size_t)W3, res);
+      flags[idx] = 0;
+    }
+  }
+}
+
 }  // namespace eccx
