@@ -64,8 +64,12 @@ def _var_unsat(n, nz, sb, a0, inv, sat_pairs, mont=True):
 WORKLOADS = {
     # name: (curve, op, per-GPU batch, algorithmic bytes per unit, multiplier instructions per unit)
     "p256r1_var_2^20": ("p256r1", "var", 1 << 20, 160, _var_unsat(9, 4, 32, 0, 383, 8 * 8 + 8 * 3)),
-    "ed25519_base_2^20": ("ed25519", "base", 1 << 20, 96, _sat(64 * 7 + 2 + (380 + 7) // 8 + 7, 8 * 8 + 8)),
-    "p256r1_base_2^20": ("p256r1", "base", 1 << 20, 96, _sat(64 * 11 + (383 + 7) // 8 + 9, 8 * 8 + 8 * 3)),
+    # fixed base, default path: 8-bit windows, 32 additions of 7 products (Edwards, saturated) or of
+    # 8 products + 3 squares (P-256, unsaturated) + conversion out, then the saturated normalisation
+    "ed25519_base_2^20": ("ed25519", "base", 1 << 20, 96, _sat(32 * 7 + (380 + 7) // 8 + 7, 8 * 8 + 8)),
+    "p256r1_base_2^20": ("p256r1", "base", 1 << 20, 96,
+                         {"mad": 32 * (8 * (81 + 36) + 3 * (45 + 36)) + 3 * (81 + 36),
+                          "pair": ((383 + 7) // 8 + 9 + 3) * (8 * 8 + 8 * 3)}),
     "x25519_2^20": ("ed25519", "x25519", 1 << 20, 96, _sat(256 * 9 + (380 + 7) // 8 + 6, 8 * 8 + 8)),
     "p384r1_var_2^19": ("p384r1", "var", 1 << 19, 240, _var_unsat(14, 12, 48, 0, 575, 12 * 12 + 12 * 10)),
     "p521r1_var_2^19": ("p521r1", "var", 1 << 19, 330, _var_unsat(18, 0, 66, 0, 780, 17 * 17, mont=False)),

@@ -383,7 +383,10 @@ int eccx_scalarmul_base_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_sc
   hipStream_t s = static_cast<hipStream_t>(stream);  // NULL = HIP's default stream
   size_t need = (n + eccx::LAUNCH_WG - 1) / eccx::LAUNCH_WG;
   int grid = (int)std::max<size_t>(1, std::min(need, (size_t)ctx->cus * 8));
-  if (!d_proj && !(opts & ECCX_MIRROR_REFERENCE) && ops->base_unsat && ctx->comb_u[curve]) {
+  // default: 8-bit windows over the engine's own wide table (the 4-bit comb of the reference's
+  // layout stays reachable through ECCX_MIRROR_REFERENCE / ECCX_TABLE_IN_LDS / ECCX_TABLE_IN_L2)
+  if (!d_proj && !(opts & (ECCX_MIRROR_REFERENCE | ECCX_TABLE_IN_LDS | ECCX_TABLE_IN_L2)) && ops->base_unsat &&
+      ctx->comb_u[curve]) {
     rc = ensure_rows(ctx, ops, n);
     if (rc) return rc;
     const int ugrid = ops->var_fast_grid ? std::max(grid, ops->var_fast_grid(ctx->cus, n)) : grid;

@@ -77,11 +77,13 @@ enum {
                                      ECCX_VALIDATE_POINTS) give unspecified output by default and
                                      the reference's arithmetic under this option. */
   ,
-  ECCX_TABLE_IN_LDS = 1u << 2,   /* fixed base, edwards25519 only: stage the whole comb table
-                                     (96 KiB) in LDS, one 1024-thread workgroup per CU, instead
-                                     of reading it through L1/L2.  Default for batches >= 2^16.
-                                     Same results; see DESIGN.md for the measured difference. */
-  ECCX_TABLE_IN_L2 = 1u << 3,    /* never stage the comb table in LDS */
+  ECCX_TABLE_IN_LDS = 1u << 2,   /* fixed base, edwards25519 only: use the reference's 4-bit comb
+                                     (64 additions) with the whole table (96 KiB) staged in LDS,
+                                     one 1024-thread workgroup per CU.  The default fixed-base
+                                     path uses 8-bit windows (32 additions) over a 768 KiB table
+                                     the engine builds for itself and reads through L2: same
+                                     results, about 1.6x faster; see DESIGN.md for the numbers. */
+  ECCX_TABLE_IN_L2 = 1u << 3,    /* fixed base: the reference's 4-bit comb, table read through L1/L2 */
   ECCX_X25519_RAW_LADDER = 1u << 4, /* eccx_x25519: raw MontgomeryPoint::scale_bytes semantics */
   ECCX_SUBTRACT = 1u << 5          /* eccx_point_add: compute a - b */
 };
