@@ -104,7 +104,7 @@ int ensure_rows(eccx_ctx* ctx, const CurveOps* ops, size_t n) {
 }
 
 int norm_grid(const eccx_ctx* ctx, size_t n) {
-  size_t tile = (size_t)eccx::LAUNCH_WG * eccx::TO_AFFINE_U;
+  size_t tile = (size_t)eccx::LAUNCH_WG * 8;  // sizing only: the kernels stride over tiles
   size_t tiles = (n + tile - 1) / tile;
   return (int)std::max<size_t>(1, std::min(tiles, (size_t)ctx->cus * 4));
 }
@@ -133,7 +133,7 @@ int launch_var(eccx_ctx* ctx, const CurveOps* ops, size_t n, const uint8_t* d_sc
     if (rc) return rc;
   }
   if (!d_proj && !(kopts & K_OUT_TABLE) && ops->to_affine_hom) {
-    // un-normalised rows, then one inversion per TO_AFFINE_U units
+    // un-normalised rows, then one inversion per to_affine_u() units
     int rc = ensure_rows(ctx, ops, n);
     if (rc) return rc;
     HIP_TRY(ctx, ops->var(grid, s, n, d_scalars, d_points, reinterpret_cast<uint8_t*>(ctx->jac), d_flags, nullptr,

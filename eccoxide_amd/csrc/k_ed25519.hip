@@ -27,7 +27,7 @@ hipError_t base_lds_(int cus, hipStream_t s, size_t n, const uint8_t* scalars, c
   return hipGetLastError();
 }
 hipError_t to_affine_hom_(int grid, hipStream_t s, size_t n, const uint32_t* rows, uint8_t* out, uint8_t* flags) {
-  hipLaunchKernelGGL((k_batch_to_affine<ED25519, NORM_EDWARDS, TO_AFFINE_U>), dim3(grid), dim3(WG), 0, s, n, rows, out, flags);
+  hipLaunchKernelGGL((k_batch_to_affine<ED25519, NORM_EDWARDS, to_affine_u(ED25519::L)>), dim3(grid), dim3(WG), 0, s, n, rows, out, flags);
   return hipGetLastError();
 }
 hipError_t comb_convert_(hipStream_t s, size_t entries, const uint8_t* affine, uint32_t* table) {
@@ -55,7 +55,7 @@ hipError_t launch_x25519_ladder(int grid, hipStream_t s, size_t n, const uint8_t
   return hipGetLastError();
 }
 hipError_t launch_x25519_to_u(int grid, hipStream_t s, size_t n, const uint32_t* rows, uint8_t* out, uint8_t* flags) {
-  hipLaunchKernelGGL((k_batch_to_affine<ED25519, NORM_MONTGOMERY_U, TO_AFFINE_U>), dim3(grid), dim3(WG), 0, s, n, rows, out,
+  hipLaunchKernelGGL((k_batch_to_affine<ED25519, NORM_MONTGOMERY_U, to_affine_u(ED25519::L)>), dim3(grid), dim3(WG), 0, s, n, rows, out,
                      flags);
   return hipGetLastError();
 }

@@ -1,6 +1,9 @@
 // Host-side launch interface between the C ABI (eccx_api.cpp) and the per-curve
 // kernel translation units (k_<curve>.hip, one per curve so they compile in parallel).
 #pragma once
+#ifndef ECCX_NORM_U8
+#define ECCX_NORM_U8 16
+#endif
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -55,7 +58,9 @@ struct CurveOps {
   hipError_t (*base_unsat)(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint32_t* utable,
                            uint32_t* rows, uint8_t* flags);
 };
-constexpr int TO_AFFINE_U = 8;  // units normalised per lane with one inversion
+// units normalised per lane with one inversion: 16 where the prefix products fit the register
+// file (8-limb fields), 8 above
+constexpr int to_affine_u(int limbs) { return limbs <= 8 ? ECCX_NORM_U8 : 8; }
 
 const CurveOps& ops_P256();
 const CurveOps& ops_P384();
