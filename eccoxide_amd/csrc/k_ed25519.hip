@@ -1,5 +1,5 @@
 // Kernel instantiations for edwards25519 (see kernels.hpp).
-#include "kernels_fast.hpp"
+#include "kernels_unsat.hpp"
 #include "launch.hpp"
 
 namespace eccx {
@@ -51,7 +51,7 @@ hipError_t point_add_(int grid, hipStream_t s, size_t n, const uint8_t* a, const
 }  // namespace
 hipError_t launch_x25519_ladder(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint8_t* u, uint32_t* rows,
                                 uint8_t* flags, uint32_t opts) {
-  hipLaunchKernelGGL(k_x25519_ladder<ED25519>, dim3(grid), dim3(WG), 0, s, n, scalars, u, rows, flags, opts);
+  hipLaunchKernelGGL(k_x25519_ladder_unsat<ED25519U>, dim3(grid), dim3(WG), 0, s, n, scalars, u, rows, flags, opts);
   return hipGetLastError();
 }
 hipError_t launch_x25519_to_u(int grid, hipStream_t s, size_t n, const uint32_t* rows, uint8_t* out, uint8_t* flags) {

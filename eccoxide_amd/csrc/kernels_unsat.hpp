@@ -427,4 +427,97 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_base_un
   }
 }
 
+// ---- curve25519 x-only Montgomery ladder (X25519) on the unsaturated field -----------------
+//   MontgomeryPoint::scale_bytes -> ladder   src/curve/curve25519.rs:535-541, :474-513
+//   protocol::x25519::x25519 (clamp, decode_u)  src/protocol/x25519.rs:14-45   [OPT_X25519_RFC]
+// Same contract as k_x25519_ladder (kernels.hpp): one differential add-and-double per scalar
+// bit, MSB first, with the reference's conditional swaps; writes (X2, X2, Z2) rows of canonical
+// integers for k_batch_to_affine<NORM_MONTGOMERY_U>.  Per step 5 products, 4 squares, one
+// small multiple and two weak reductions; sums and differences stay lazy.
+template <class CU>
+__global__ void __launch_bounds__(WG, 4) k_x25519_ladder_unsat(size_t n, const uint8_t* __restrict__ scalars,
+                                                               const uint8_t* __restrict__ u_in,
+                                                               uint32_t* __restrict__ rows_out, uint8_t* __restrict__ flags,
+                                                               uint32_t opts) {
+  using CS = typename CU::Sat;
+  constexpr int L = CS::L;
+  using T = U<CU, 1, 3>;
+  const bool rfc = (opts & OPT_X25519_RFC) != 0;
+  for (size_t base = (size_t)blockIdx.x * WG; base < n; base += (size_t)gridDim.x * WG) {
+    const size_t gid = base + threadIdx.x;
+    const bool active = gid < n;
+    const size_t idx = active ? gid : n - 1;
+    T x1, x2, z2, x3, z3;
+    {
+      Fe<L> raw;
+      if (u_in) {
+        fe_load_le<CS>(raw, u_in + idx * 32);
+        if (rfc) raw.v[L - 1] &= 0x7fffffffu;  // decode_u masks the unused top bit
+      } else {
+        fe_zero<CS>(raw);
+        raw.v[0] = 9;  // MONT_GU_BYTES
+      }
+      // any 256-bit string is accepted and taken modulo p
+      x1 = u_reduce(u_as<1, 3>(u_from_sat<CU>(raw)));
+    }
+    u_set_zero(x2);
+    x2.v[0] = 1;
+    u_set_zero(z2);
+    x3 = x1;
+    u_set_zero(z3);
+    z3.v[0] = 1;
+    const uint8_t* __restrict__ k = scalars + idx * 32;
+    uint32_t swap = 0;
+    for (int t = 255; t >= 0; --t) {
+      uint32_t bit;
+      if (rfc) {  // little-endian scalar, clamped: k[0] &= 248, k[31] &= 127, k[31] |= 64
+        bit = (k[t >> 3] >> (t & 7)) & 1u;
+        if (t == 255 || t < 3) bit = 0;
+        if (t == 254) bit = 1;
+      } else {    // the big-endian string the ladder consumes
+        bit = (k[31 - (t >> 3)] >> (t & 7)) & 1u;
+      }
+      swap ^= bit;
+      {
+        const bool sw = swap != 0;
+        T a = x2, b = x3;
+        u_select(x2, sw, b, a);
+        u_select(x3, sw, a, b);
+        a = z2; b = z3;
+        u_select(z2, sw, b, a);
+        u_select(z3, sw, a, b);
+      }
+      swap = bit;
+      auto a = u_add(x2, z2);
+      auto aa = u_sqr(a);
+      auto b = u_reduce(u_sub(x2, z2));
+      auto bb = u_sqr(b);
+      auto e = u_sub(aa, bb);
+      auto c = u_add(x3, z3);
+      auto d = u_sub(x3, z3);
+      auto da = u_mul(d, a);
+      auto cb = u_mul(c, b);
+      x3 = u_fit<1, 3>(u_sqr(u_add(da, cb)));
+      z3 = u_fit<1, 3>(u_mul(x1, u_sqr(u_sub(da, cb))));
+      x2 = u_fit<1, 3>(u_mul(aa, bb));
+      auto s = u_add(bb, u_mul_small(e, 121666u));  // bb + a24 * e
+      z2 = u_fit<1, 3>(u_mul(e, s));
+    }
+    {
+      const bool sw = swap != 0;
+      T a = x2, b = z2;
+      u_select(x2, sw, x3, a);
+      u_select(z2, sw, z3, b);
+    }
+    if (active) {
+      Pt<CS> row;
+      u_to_canonical<CU>(row.x, x2);
+      row.y = row.x;
+      u_to_canonical<CU>(row.z, z2);
+      row_store<CS>(rows_out + idx * (size_t)row_words<L>(), row);
+      flags[idx] = 0;
+    }
+  }
+}
+
 }  // namespace eccx

@@ -15,6 +15,9 @@
 //   1  Montgomery, general p (BLS12-381): m = acc * (-p^-1) mod 2^B   (src/curve/fiat/bls12_381_*.rs)
 //   2  p = 2^k - 1 (P-521), plain representation: the wrapped half of the product is
 //      accumulated into the same columns with weight 2^(B*N - k)          (src/curve/fiat/p521_64.rs)
+//   3  p = 2^255 - 19, plain representation, 9 x 29 = 261 bits: the upper columns are carried
+//      into digits first and enter the lower columns times 2^261 mod p = 1216
+//                                                          (src/curve/fiat/curve25519_64.rs)
 //
 // The price is bookkeeping, done at compile time.  Every value carries two bounds in its
 // type, U<C, K, V>:
@@ -38,7 +41,7 @@ namespace eccx {
 
 #include "umad_chunks.inc"
 
-enum : int { UK_MONT_PP1 = 0, UK_MONT = 1, UK_MERSENNE = 2 };
+enum : int { UK_MONT_PP1 = 0, UK_MONT = 1, UK_MERSENNE = 2, UK_PM19 = 3 };
 
 template <class C, int K, int V>
 struct U {
@@ -50,20 +53,24 @@ struct U {
 // what the multiplier columns and the 32-bit limbs can take
 template <class C>
 struct UB {
-  static constexpr bool MONT = C::KIND != UK_MERSENNE;
+  static constexpr bool MONT = C::KIND == UK_MONT_PP1 || C::KIND == UK_MONT;
+  static constexpr bool WRAPPED = C::KIND == UK_MERSENNE;  // both halves of the product share the columns
   static constexpr int KMAX = (1 << (32 - C::B)) - 1;
   static constexpr uint64_t COL = (uint64_t)1 << (2 * C::B);  // one product of tight limbs
   // largest K1*K2 a product may have: Montgomery columns hold N products + N reduction
   // products; the Mersenne columns hold N direct products + N - 1 doubled wrapped ones
-  static constexpr int KKMAX = MONT ? (int)(~(uint64_t)0 / ((uint64_t)C::N * COL)) - 1
-                                    : (int)(~(uint64_t)0 / ((uint64_t)(2 * C::N - 1) * COL));
+  // (kind 3: N products + one folded digit times 1216)
+  static constexpr int KKMAX = !WRAPPED ? (int)(~(uint64_t)0 / ((uint64_t)C::N * COL)) - 1
+                                        : (int)(~(uint64_t)0 / ((uint64_t)(2 * C::N - 1) * COL));
   static_assert(KKMAX >= 1, "limbs too wide for this many columns");
   static constexpr bool kk_ok(int k1, int k2) { return k1 * k2 <= KKMAX; }
   // squares also shift the operand left by one (two for the wrapped cross terms)
-  static constexpr int KSQ_SHIFT = MONT ? 1 : 2;
+  static constexpr int KSQ_SHIFT = WRAPPED ? 2 : 1;
   static constexpr bool ksq_ok(int k) { return k * k <= KKMAX && (k << KSQ_SHIFT) <= KMAX + 1; }
   // bound of a product of values below v1*p and v2*p
-  static constexpr int vout(int v1, int v2) { return MONT ? (int)(((uint32_t)(v1 * v2) + C::RP - 1) / C::RP) + 1 : 3; }
+  static constexpr int vout(int v1, int v2) {
+    return MONT ? (int)(((uint32_t)(v1 * v2) + C::RP - 1) / C::RP) + 1 : (C::KIND == UK_PM19 ? 2 : 3);
+  }
   // laziest limb bound a value may have and still be squared / multiplied by a tight value
   static constexpr int KLAZY = ksq_ok(2) ? 2 : 1;
 };
@@ -221,9 +228,73 @@ ECCX_DEV void u_mul_core_mers(uint32_t (&r)[C::N], const uint32_t (&a)[C::N], co
   for (int i = 0; i < N; ++i) r[i] = t[i];
 }
 
+// 2^255 - 19 (kind 3): tail shared by the product and the small multiple.  t holds the lower
+// digits, c what the column chain left above them (weight 2^(B*N) = FOLD); afterwards the bits
+// of the top limb above 2^255 are folded too (times 19), so the value is below 2^255 + 2^46.
+template <class C>
+ECCX_DEV void u_pm_tail(uint32_t (&t)[C::N], uint64_t c) {
+  constexpr int N = C::N;
+  static_assert(C::FOLD == (19u << (C::B * N - 255)), "fold factor");
+  uint64_t acc = c * C::FOLD + t[0];
+  t[0] = (uint32_t)acc & C::MASK;
+  t[1] += (uint32_t)(acc >> C::B);
+  const uint32_t q = t[N - 1] >> C::TOPSHIFT;
+  t[N - 1] &= (1u << C::TOPSHIFT) - 1u;
+  t[0] += 19u * q;
+}
+
+template <class C, bool SQR, bool BCONST>
+ECCX_DEV void u_mul_core_pm(uint32_t (&r)[C::N], const uint32_t (&a)[C::N], const uint32_t (&b)[C::N]) {
+  constexpr int N = C::N;
+  uint32_t h[N], t[N], a2[N];
+  if constexpr (SQR) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) a2[i] = a[i] << 1;
+  }
+  UMacQ<BCONST> qa;
+  // upper columns k = N .. 2N-2 as a number of their own: digits h[0 .. N-1]
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = N; k < 2 * N - 1; ++k) {
+    if constexpr (SQR) {
+#pragma unroll
+      for (int i = k - N + 1; 2 * i < k; ++i) qa.push(acc, a[i], a2[k - i]);
+      if ((k & 1) == 0) qa.push(acc, a[k / 2], a[k / 2]);
+    } else {
+#pragma unroll
+      for (int i = k - N + 1; i < N; ++i) qa.push(acc, a[i], b[k - i]);
+    }
+    qa.flush(acc);
+    h[k - N] = (uint32_t)acc & C::MASK;
+    acc >>= C::B;
+  }
+  h[N - 1] = (uint32_t)acc;
+  // lower columns, each taking its upper digit times 2^(B*N) mod p
+  acc = 0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    if constexpr (SQR) {
+#pragma unroll
+      for (int i = 0; 2 * i < k; ++i) qa.push(acc, a[i], a2[k - i]);
+      if ((k & 1) == 0) qa.push(acc, a[k / 2], a[k / 2]);
+    } else {
+#pragma unroll
+      for (int i = 0; i <= k; ++i) qa.push(acc, a[i], b[k - i]);
+    }
+    qa.flush(acc);
+    umad1_k(acc, h[k], C::FOLD);
+    t[k] = (uint32_t)acc & C::MASK;
+    acc >>= C::B;
+  }
+  u_pm_tail<C>(t, acc);
+#pragma unroll
+  for (int i = 0; i < N; ++i) r[i] = t[i];
+}
+
 template <class C, bool SQR, bool BCONST>
 ECCX_DEV void u_mul_core(uint32_t (&r)[C::N], const uint32_t (&a)[C::N], const uint32_t (&b)[C::N]) {
   if constexpr (C::KIND == UK_MERSENNE) u_mul_core_mers<C, SQR, BCONST>(r, a, b);
+  else if constexpr (C::KIND == UK_PM19) u_mul_core_pm<C, SQR, BCONST>(r, a, b);
   else u_mul_core_mont<C, SQR, BCONST>(r, a, b);
 }
 
@@ -239,10 +310,11 @@ ECCX_DEV U<C, 1, 3> u_reduce(const U<C, K1, V1>& a) {
   if constexpr (C::QMUL != 0) q = __umulhi(top, C::QMUL);
   else q = top >> C::TOPSHIFT;
   U<C, 1, 3> r;
-  if constexpr (C::KIND == UK_MERSENNE) {
-    // q * p = q * 2^PBITS - q: q enters at the bottom, q << TOPSHIFT leaves at the top; every
-    // partial sum is non-negative and below 2^32, so the chain is plain 32-bit arithmetic
-    uint32_t c = q;
+  if constexpr (C::KIND == UK_MERSENNE || C::KIND == UK_PM19) {
+    // q * p = q * 2^PBITS - q * (2^PBITS - p): q (or 19 q) enters at the bottom, q << TOPSHIFT
+    // leaves at the top; every partial sum is non-negative and below 2^32, so the chain is
+    // plain 32-bit arithmetic
+    uint32_t c = (C::KIND == UK_PM19) ? 19u * q : q;
 #pragma unroll
     for (int i = 0; i < N - 1; ++i) {
       const uint32_t t = a.v[i] + c;
@@ -320,6 +392,26 @@ ECCX_DEV auto u_mul_k(const U<C, K1, V1>& a, const uint32_t (&k)[C::N]) {
     u_mul_core<C, false, true>(r.v, a.v, k);
     return r;
   }
+}
+
+// multiply by a small constant k < 2^20 (kind 3 only: the ladder's (A + 2) / 4): one mad per limb
+template <class C, int K1, int V1>
+ECCX_DEV U<C, 1, 2> u_mul_small(const U<C, K1, V1>& a, uint32_t k) {
+  static_assert(C::KIND == UK_PM19, "written for 2^255 - 19");
+  constexpr int N = C::N;
+  uint32_t t[N];
+  uint64_t acc = 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    umad1_v(acc, a.v[i], k);
+    t[i] = (uint32_t)acc & C::MASK;
+    acc >>= C::B;
+  }
+  u_pm_tail<C>(t, acc);
+  U<C, 1, 2> r;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.v[i] = t[i];
+  return r;
 }
 
 template <class C, int K1, int V1, int K2, int V2>

@@ -98,6 +98,7 @@ int fieldcheck_info(int curve, int* info) {
     case 1: ECCX_INFO(P384U)
     case 2: ECCX_INFO(P521U)
     case 3: ECCX_INFO(BLS12_381U)
+    case 4: ECCX_INFO(ED25519U)
     default: return -1;
   }
 #undef ECCX_INFO
@@ -124,6 +125,7 @@ int fieldcheck_run(int curve, int op, const uint32_t* a, const uint32_t* b, uint
     case 1: hipLaunchKernelGGL(k_field_check<P384U>, dim3(grid), dim3(wg), 0, 0, op, da, db, dout, n); break;
     case 2: hipLaunchKernelGGL(k_field_check<P521U>, dim3(grid), dim3(wg), 0, 0, op, da, db, dout, n); break;
     case 3: hipLaunchKernelGGL(k_field_check<BLS12_381U>, dim3(grid), dim3(wg), 0, 0, op, da, db, dout, n); break;
+    case 4: hipLaunchKernelGGL(k_field_check<ED25519U>, dim3(grid), dim3(wg), 0, 0, op, da, db, dout, n); break;
     default: break;
   }
   e = hipGetLastError();

@@ -66,11 +66,12 @@ def digits(x, bits, n):
     return [(x >> (bits * i)) & ((1 << bits) - 1) for i in range(n)]
 
 
-def emit_unsat(out, name, sat_name, p, gx, gy, bits, n, kind):
+def emit_unsat(out, name, sat_name, p, gx, gy, bits, n, kind, extra=()):
     """Constants of the unsaturated representation: n limbs of `bits` bits in 32-bit registers.
     kind 0: Montgomery, R = 2^(bits*n), p = -1 mod 2^bits (reduce with the digits of p + 1)
     kind 1: Montgomery, general p (m = acc * N0B mod 2^bits)
     kind 2: p = 2^k - 1, plain representation, 2^(bits*n) = 2^(bits*n - k) mod p folded into the product
+    kind 3: p = 2^255 - 19, plain representation, 2^(bits*n) = 19 * 2^(bits*n - 255) mod p
     BIAS is 4p written with every limb >= 2^bits - 1 (the largest tight limb) so that
     a + BIAS - b never borrows for tight b < 3p."""
     mont = kind in (0, 1)
@@ -85,7 +86,7 @@ def emit_unsat(out, name, sat_name, p, gx, gy, bits, n, kind):
     assert sum(b << (bits * i) for i, b in enumerate(bias)) == 4 * p
     assert all(b >= (1 << bits) - 1 for b in bias[:-1]) and all(b < (1 << (bits + 1)) for b in bias)
     # a tight value below 3p (Montgomery kinds) or below 2^(bits*n) (plain kinds) has a top digit <= bias top
-    top_tight = ((3 * p) >> (bits * (n - 1))) if mont else (1 << bits) - 1
+    top_tight = ((3 * p) >> (bits * (n - 1))) if (mont or kind == 3) else (1 << bits) - 1
     assert bias[-1] >= top_tight, (name, hex(bias[-1]), hex(top_tight))
     topshift = pbits - bits * (n - 1)
     assert 0 < topshift < bits
@@ -97,7 +98,8 @@ def emit_unsat(out, name, sat_name, p, gx, gy, bits, n, kind):
     out.append("  using Sat = %s;          // saturated twin (byte I/O, validation, normalisation)" % sat_name)
     out.append("  static constexpr int N = %d;     // limbs" % n)
     out.append("  static constexpr int B = %d;    // bits per limb" % bits)
-    out.append("  static constexpr int KIND = %d;  // 0 Montgomery p = -1 mod 2^B, 1 Montgomery general, 2 Mersenne (plain)" % kind)
+    out.append("  static constexpr int KIND = %d;  // 0 Montgomery p = -1 mod 2^B, 1 Montgomery general, 2 Mersenne (plain), 3 2^255-19 (plain)" % kind)
+    out.append("  static constexpr uint32_t FOLD = %du;  // 2^(B*N) mod p where that is small (kinds 2, 3), else 0" % ((1 << (bits * n)) % p if kind in (2, 3) else 0))
     out.append("  static constexpr int PBITS = %d;" % pbits)
     out.append("  static constexpr int TOPSHIFT = %d;  // bit PBITS inside the top limb" % topshift)
     out.append("  static constexpr uint32_t QMUL = 0x%08xu;  // 0: quotient estimate is a shift" % qmul)
@@ -114,6 +116,8 @@ def emit_unsat(out, name, sat_name, p, gx, gy, bits, n, kind):
     out.append(arr("BIAS", bias))
     out.append(arr("GX", digits(gx * R % p, bits, n)))
     out.append(arr("GY", digits(gy * R % p, bits, n)))
+    for cname, val in extra:
+        out.append(arr(cname, digits(val * R % p, bits, n)))
     out.append("};")
     out.append("")
 
@@ -140,6 +144,8 @@ def main():
     emit_unsat(out, "P521U", "P521", CURVES[2][1], CURVES[2][3], CURVES[2][4], 29, 18, 2)
     emit_unsat(out, "BLS12_381U", "BLS12_381", CURVES[3][1], CURVES[3][3], CURVES[3][4], 28, 14, 1)
     L = 8
+    out.append("struct ED25519;")
+    emit_unsat(out, "ED25519U", "ED25519", P25519, ED_GX, ED_GY, 29, 9, 3, extra=(("D2", 2 * ED_D % P25519),))
     out.append("struct ED25519 {")
     out.append("  static constexpr int L = 8;")
     out.append("  static constexpr int FB = 32;")
