@@ -64,9 +64,10 @@ def _var_unsat(n, nz, sb, a0, inv, sat_pairs, mont=True):
 WORKLOADS = {
     # name: (curve, op, per-GPU batch, algorithmic bytes per unit, multiplier instructions per unit)
     "p256r1_var_2^20": ("p256r1", "var", 1 << 20, 160, _var_unsat(9, 4, 32, 0, 383, 8 * 8 + 8 * 3)),
-    # fixed base, default path: 8-bit windows, 32 additions of 7 products (Edwards, saturated) or of
-    # 8 products + 3 squares (P-256, unsaturated) + conversion out, then the saturated normalisation
-    "ed25519_base_2^20": ("ed25519", "base", 1 << 20, 96, _sat(32 * 7 + (380 + 7) // 8 + 7, 8 * 8 + 8)),
+    # fixed base, default path: 8-bit windows, 32 additions of 7 products (Edwards, 81 + 9 mads each) or
+    # of 8 products + 3 squares (P-256) on unsaturated limbs, then the saturated normalisation
+    "ed25519_base_2^20": ("ed25519", "base", 1 << 20, 96,
+                          {"mad": 32 * 7 * (81 + 9), "pair": ((380 + 15) // 16 + 7) * (8 * 8 + 8)}),
     "p256r1_base_2^20": ("p256r1", "base", 1 << 20, 96,
                          {"mad": 32 * (8 * (81 + 36) + 3 * (45 + 36)) + 3 * (81 + 36),
                           "pair": ((383 + 7) // 8 + 9 + 3) * (8 * 8 + 8 * 3)}),

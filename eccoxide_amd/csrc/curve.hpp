@@ -134,21 +134,6 @@ ECCX_DEV void ed_add_cached(EdPt<C>& r, const EdPt<C>& p, const Fe<C::L>& x2, co
   M_(r.x, e, f); M_(r.y, g, h); M_(r.z, f, g); M_(r.t, e, h);
 }
 
-// r = p + (x2, y2) given as the precomputed triple (y2 - x2, y2 + x2, 2d*x2*y2): 7 products and
-// no operand preparation (the "Niels" form of the same cached addition)
-template <class C>
-ECCX_DEV void ed_add_niels(EdPt<C>& r, const EdPt<C>& p, const Fe<C::L>& ym, const Fe<C::L>& yp,
-                           const Fe<C::L>& t2d) {
-  using F = Fe<C::L>;
-  F aa, bb, cc, dd, e, f, g, h, u;
-  S_(u, p.y, p.x); M_(aa, u, ym);
-  A_(u, p.y, p.x); M_(bb, u, yp);
-  M_(cc, p.t, t2d);
-  A_(dd, p.z, p.z);
-  S_(e, bb, aa); S_(f, dd, cc); A_(g, dd, cc); A_(h, bb, aa);
-  M_(r.x, e, f); M_(r.y, g, h); M_(r.z, f, g); M_(r.t, e, h);
-}
-
 template <class C>
 ECCX_DEV void ed_dbl(EdPt<C>& r, const EdPt<C>& p) {
   using F = Fe<C::L>;

@@ -254,25 +254,6 @@ ECCX_DEV void fe_mul_pm19(Fe<C::L>& r, const Fe<C::L>& a, const uint32_t (&b)[C:
   cond_sub_p<C>(r, u, 0u);  // u < 2^255 + 19 * 80 < 2p
 }
 
-// r = a * k mod 2^255 - 19 for a small constant k < 2^17 (the ladder's a24 = 121666)
-template <class C>
-ECCX_DEV void fe_mul_small_pm19(Fe<C::L>& r, const Fe<C::L>& a, uint32_t k) {
-  constexpr int L = C::L;
-  uint32_t u[L];
-  uint64_t acc = 0;
-#pragma unroll
-  for (int i = 0; i < L; ++i) {
-    acc = (uint64_t)a.v[i] * k + (acc >> 32);
-    u[i] = (uint32_t)acc;
-  }
-  uint32_t top = ((uint32_t)(acc >> 32) << 1) | (u[L - 1] >> 31);  // < 2^18
-  u[L - 1] &= 0x7fffffffu;
-  uint32_t c = 0;
-  u[0] = addc(u[0], top * 19u, c);
-#pragma unroll
-  for (int i = 1; i < L; ++i) u[i] = addc(u[i], 0u, c);
-  cond_sub_p<C>(r, u, 0u);
-}
 
 template <class C, bool BCONST = false>
 ECCX_DEV void fe_mul_impl(Fe<C::L>& r, const Fe<C::L>& a, const uint32_t (&b)[C::L]) {

@@ -31,12 +31,12 @@ hipError_t to_affine_hom_(int grid, hipStream_t s, size_t n, const uint32_t* row
   return hipGetLastError();
 }
 hipError_t comb_convert_(hipStream_t s, size_t entries, const uint8_t* affine, uint32_t* table) {
-  hipLaunchKernelGGL(k_ed_affine_to_niels<ED25519>, dim3((unsigned)((entries + 127) / 128)), dim3(128), 0, s, entries, affine, table);
+  hipLaunchKernelGGL(k_ed_affine_to_niels_unsat<ED25519U>, dim3((unsigned)((entries + 127) / 128)), dim3(128), 0, s, entries, affine, table);
   return hipGetLastError();
 }
 hipError_t base_w8_(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint32_t* table, uint32_t* rows,
                     uint8_t* flags) {
-  hipLaunchKernelGGL(k_ed_scalarmul_base_w8<ED25519>, dim3(grid), dim3(WG), 0, s, n, scalars, table, rows, flags);
+  hipLaunchKernelGGL(k_ed_scalarmul_base_unsat<ED25519U>, dim3(grid), dim3(WG), 0, s, n, scalars, table, rows, flags);
   return hipGetLastError();
 }
 int var_grid_(int cus, size_t n) {
@@ -60,7 +60,7 @@ hipError_t launch_x25519_to_u(int grid, hipStream_t s, size_t n, const uint32_t*
   return hipGetLastError();
 }
 const CurveOps& ops_ED25519() {
-  static const CurveOps o = {{ED25519::FB, ED25519::SB, ED25519::L, 4 * ED25519::L, 0, 1, 0, row_words<ED25519::L>()}, var_, base_, nullptr, nullptr, nullptr, base_lds_, to_affine_hom_, var_grid_, nullptr, to_affine_hom_, point_add_, ED_W8_ENTRY_WORDS, comb_convert_, base_w8_};
+  static const CurveOps o = {{ED25519::FB, ED25519::SB, ED25519::L, 4 * ED25519::L, 0, 1, 0, row_words<ED25519::L>()}, var_, base_, nullptr, nullptr, nullptr, base_lds_, to_affine_hom_, var_grid_, nullptr, to_affine_hom_, point_add_, ED_U_ENTRY_WORDS, comb_convert_, base_w8_};
   return o;
 }
 }  // namespace eccx

@@ -446,88 +446,7 @@ __global__ void __launch_bounds__(WG) k_ed_point_add(size_t n, const uint8_t* __
   }
 }
 
-// ---- curve25519 x-only Montgomery ladder (X25519) -------------------------------------
-//   MontgomeryPoint::scale_bytes -> ladder   src/curve/curve25519.rs:535-541, :474-513
-//   protocol::x25519::x25519 (clamp, decode_u)  src/protocol/x25519.rs:14-45   [OPT_X25519_RFC]
-// One differential add-and-double per scalar bit, MSB first, with the reference's
-// conditional swaps; writes (X2, X2, Z2) rows for k_batch_to_affine<NORM_MONTGOMERY_U>, which
-// applies invert_or_zero (Z = 0 -> u = 0).
+// ---- curve25519 x-only Montgomery ladder (X25519): k_x25519_ladder_unsat, kernels_unsat.hpp
 enum : uint32_t { OPT_X25519_RFC = 1u << 4 };
-
-template <class C>
-__global__ void __launch_bounds__(WG) k_x25519_ladder(size_t n, const uint8_t* __restrict__ scalars,
-                                                      const uint8_t* __restrict__ u_in,
-                                                      uint32_t* __restrict__ rows_out, uint8_t* __restrict__ flags,
-                                                      uint32_t opts) {
-  constexpr int L = C::L;
-  const bool rfc = (opts & OPT_X25519_RFC) != 0;
-  for (size_t base = (size_t)blockIdx.x * WG; base < n; base += (size_t)gridDim.x * WG) {
-    const size_t gid = base + threadIdx.x;
-    const bool active = gid < n;
-    const size_t idx = active ? gid : n - 1;
-    Fe<L> x1, x2, z2, x3, z3;
-    {
-      Fe<L> raw;
-      if (u_in) {
-        fe_load_le<C>(raw, u_in + idx * 32);
-        if (rfc) raw.v[L - 1] &= 0x7fffffffu;  // decode_u masks the unused top bit
-      } else {
-        fe_zero<C>(raw);
-        raw.v[0] = 9;  // MONT_GU_BYTES
-      }
-      fe_to_mont<C>(x1, raw);  // reduces mod p
-    }
-    fe_set<C>(x2, C::ONE);
-    fe_zero<C>(z2);
-    x3 = x1;
-    fe_set<C>(z3, C::ONE);
-    const uint8_t* __restrict__ k = scalars + idx * 32;
-    uint32_t swap = 0;
-    for (int t = 255; t >= 0; --t) {
-      uint32_t bit;
-      if (rfc) {  // little-endian scalar, clamped: k[0] &= 248, k[31] &= 127, k[31] |= 64
-        bit = (k[t >> 3] >> (t & 7)) & 1u;
-        if (t == 255 || t < 3) bit = 0;
-        if (t == 254) bit = 1;
-      } else {    // the big-endian string the ladder consumes
-        bit = (k[31 - (t >> 3)] >> (t & 7)) & 1u;
-      }
-      swap ^= bit;
-      {
-        const bool sw = swap != 0;
-        Fe<L> a = x2, b = x3;
-        fe_select<C>(x2, sw, b, a);
-        fe_select<C>(x3, sw, a, b);
-        a = z2; b = z3;
-        fe_select<C>(z2, sw, b, a);
-        fe_select<C>(z3, sw, a, b);
-      }
-      swap = bit;
-      Fe<L> a, aa, b, bb, e, c, d, da, cb, s;
-      fe_add<C>(a, x2, z2); fe_sqr<C>(aa, a);
-      fe_sub<C>(b, x2, z2); fe_sqr<C>(bb, b);
-      fe_sub<C>(e, aa, bb);
-      fe_add<C>(c, x3, z3); fe_sub<C>(d, x3, z3);
-      fe_mul<C>(da, d, a); fe_mul<C>(cb, c, b);
-      fe_add<C>(s, da, cb); fe_sqr<C>(x3, s);
-      fe_sub<C>(s, da, cb); fe_sqr<C>(s, s); fe_mul<C>(z3, x1, s);
-      fe_mul<C>(x2, aa, bb);
-      fe_mul_small_pm19<C>(s, e, 121666u);  // a24 * e
-      fe_add<C>(s, bb, s); fe_mul<C>(z2, e, s);
-    }
-    {
-      const bool sw = swap != 0;
-      Fe<L> a = x2, b = z2;
-      fe_select<C>(x2, sw, x3, a);
-      fe_select<C>(z2, sw, z3, b);
-    }
-    if (active) {
-      Pt<C> row;
-      row.x = x2; row.y = x2; row.z = z2;
-      row_store<C>(rows_out + idx * (size_t)row_words<L>(), row);
-      flags[idx] = 0;
-    }
-  }
-}
 
 }  // namespace eccx

@@ -257,63 +257,6 @@ __global__ void __launch_bounds__(WG) k_scalarmul_base_fast(size_t n, const uint
   }
 }
 
-// edwards25519 fixed base with 8-bit windows.  The reference's mul_base (curve25519.rs:840-851)
-// adds one table entry per 4-bit window; k*B does not depend on the window width, so the
-// default path uses one entry per scalar BYTE -- entry (w, d) = d * 256^w * B as the triple
-// (y - x, y + x, 2d*x*y), d = 0 being the neutral (1, 1, 0) -- from a table the engine builds
-// for itself (32 x 256 entries of 96 B, L2 resident): 32 seven-product additions instead of 64.
-constexpr int ED_W8_ENTRY_WORDS = 24;
-template <class C>
-__global__ void k_ed_affine_to_niels(size_t entries, const uint8_t* __restrict__ affine, uint32_t* __restrict__ table) {
-  constexpr int L = C::L;
-  static_assert(3 * L == ED_W8_ENTRY_WORDS, "entry layout");
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= entries) return;
-  Fe<L> x, y, ym, yp, t, t2d;
-  fe_load_le<C>(x, affine + i * 64);
-  fe_load_le<C>(y, affine + i * 64 + 32);
-  fe_to_mont<C>(x, x);
-  fe_to_mont<C>(y, y);
-  fe_sub<C>(ym, y, x);
-  fe_add<C>(yp, y, x);
-  fe_mul<C>(t, x, y);
-  fe_mul_k<C>(t2d, t, C::D2);
-  uint32_t* o = table + i * ED_W8_ENTRY_WORDS;
-#pragma unroll
-  for (int k = 0; k < L; ++k) { o[k] = ym.v[k]; o[L + k] = yp.v[k]; o[2 * L + k] = t2d.v[k]; }
-}
-
-template <class C>
-__global__ void __launch_bounds__(WG) k_ed_scalarmul_base_w8(size_t n, const uint8_t* __restrict__ scalars,
-                                                             const uint32_t* __restrict__ table,
-                                                             uint32_t* __restrict__ rows_out, uint8_t* __restrict__ flags) {
-  constexpr int L = C::L;
-  for (size_t base = (size_t)blockIdx.x * WG; base < n; base += (size_t)gridDim.x * WG) {
-    const size_t gid = base + threadIdx.x;
-    const bool active = gid < n;
-    const size_t idx = active ? gid : n - 1;
-    const uint8_t* __restrict__ k = scalars + idx * 32;
-    EdPt<C> q;
-    ed_set_identity<C>(q);
-    for (int w = 0; w < 32; ++w) {
-      const uint32_t d = k[31 - w];  // big-endian scalar bytes (curve25519.rs:842-846)
-      const uint4* __restrict__ e = reinterpret_cast<const uint4*>(table + ((size_t)w * 256 + d) * ED_W8_ENTRY_WORDS);
-      uint32_t ew[ED_W8_ENTRY_WORDS];
-#pragma unroll
-      for (int i = 0; i < ED_W8_ENTRY_WORDS / 4; ++i) {
-        const uint4 v = e[i];
-        ew[4 * i] = v.x; ew[4 * i + 1] = v.y; ew[4 * i + 2] = v.z; ew[4 * i + 3] = v.w;
-      }
-      Fe<L> ym, yp, t2d;
-#pragma unroll
-      for (int i = 0; i < L; ++i) { ym.v[i] = ew[i]; yp.v[i] = ew[L + i]; t2d.v[i] = ew[2 * L + i]; }
-      ed_add_niels<C>(q, q, ym, yp, t2d);
-    }
-    if (active)
-      ed_store_result<C>(idx, q, false, reinterpret_cast<uint8_t*>(rows_out), flags, nullptr, OPT_OUT_ROWS);
-  }
-}
-
 // edwards25519 fixed base with the whole comb table staged in LDS (BASELINE.json configs[2]:
 // "comb table in LDS").  One 1024-thread workgroup per CU shares a 96 KiB image of the table
 // (64 windows x 16 digits x {x, y, 2d*x*y}, digit 0 = the neutral element so the loop has no

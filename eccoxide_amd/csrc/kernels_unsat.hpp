@@ -430,9 +430,9 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_base_un
 // ---- curve25519 x-only Montgomery ladder (X25519) on the unsaturated field -----------------
 //   MontgomeryPoint::scale_bytes -> ladder   src/curve/curve25519.rs:535-541, :474-513
 //   protocol::x25519::x25519 (clamp, decode_u)  src/protocol/x25519.rs:14-45   [OPT_X25519_RFC]
-// Same contract as k_x25519_ladder (kernels.hpp): one differential add-and-double per scalar
-// bit, MSB first, with the reference's conditional swaps; writes (X2, X2, Z2) rows of canonical
-// integers for k_batch_to_affine<NORM_MONTGOMERY_U>.  Per step 5 products, 4 squares, one
+// One differential add-and-double per scalar bit, MSB first, with the reference's conditional
+// swaps; writes (X2, X2, Z2) rows of canonical integers for k_batch_to_affine<NORM_MONTGOMERY_U>,
+// which applies invert_or_zero (Z = 0 -> u = 0).  Per step 5 products, 4 squares, one
 // small multiple and two weak reductions; sums and differences stay lazy.
 template <class CU>
 __global__ void __launch_bounds__(WG, 4) k_x25519_ladder_unsat(size_t n, const uint8_t* __restrict__ scalars,
@@ -514,6 +514,92 @@ __global__ void __launch_bounds__(WG, 4) k_x25519_ladder_unsat(size_t n, const u
       u_to_canonical<CU>(row.x, x2);
       row.y = row.x;
       u_to_canonical<CU>(row.z, z2);
+      row_store<CS>(rows_out + idx * (size_t)row_words<L>(), row);
+      flags[idx] = 0;
+    }
+  }
+}
+
+// ---- edwards25519 fixed base, 8-bit windows, unsaturated field ------------------------------
+// The reference's mul_base (curve25519.rs:840-851) adds one table entry per 4-bit window; k*B
+// does not depend on the window width, so the default path uses one entry per scalar BYTE --
+// entry (w, d) = d * 256^w * B as the triple (y - x, y + x, 2d*x*y), d = 0 being the neutral
+// (1, 1, 0) -- from a table the engine builds for itself (32 x 256 entries of 9 x 29-bit digits,
+// 28 words each, L2 resident): 32 seven-product additions instead of 64.  The only carry chain
+// per addition is the reduction of F = 2Z - C, which feeds two products.
+constexpr int ED_U_ENTRY_WORDS = 28;
+template <class CU>
+__global__ void k_ed_affine_to_niels_unsat(size_t entries, const uint8_t* __restrict__ affine, uint32_t* __restrict__ table) {
+  using CS = typename CU::Sat;
+  constexpr int L = CS::L;
+  constexpr int N = CU::N;
+  static_assert(3 * N <= ED_U_ENTRY_WORDS, "entry layout");
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= entries) return;
+  Fe<L> fx, fy;
+  fe_load_le<CS>(fx, affine + i * 64);
+  fe_load_le<CS>(fy, affine + i * 64 + 32);
+  const auto x = u_from_sat<CU>(fx);
+  const auto y = u_from_sat<CU>(fy);
+  U<CU, 1, 2> d2;
+#pragma unroll
+  for (int k = 0; k < N; ++k) d2.v[k] = CU::D2[k];
+  const auto ym = u_reduce(u_sub(y, x));
+  const auto yp = u_reduce(u_add(y, x));
+  const auto t2d = u_reduce(u_mul(u_mul(x, y), d2));
+  uint32_t* o = table + i * ED_U_ENTRY_WORDS;
+#pragma unroll
+  for (int k = 0; k < ED_U_ENTRY_WORDS; ++k)
+    o[k] = k < N ? ym.v[k] : (k < 2 * N ? yp.v[k - N] : (k < 3 * N ? t2d.v[k - 2 * N] : 0u));
+}
+
+template <class CU>
+__global__ void __launch_bounds__(WG, 4) k_ed_scalarmul_base_unsat(size_t n, const uint8_t* __restrict__ scalars,
+                                                                   const uint32_t* __restrict__ table,
+                                                                   uint32_t* __restrict__ rows_out, uint8_t* __restrict__ flags) {
+  using CS = typename CU::Sat;
+  constexpr int L = CS::L;
+  constexpr int N = CU::N;
+  using T = U<CU, 1, 3>;
+  for (size_t base = (size_t)blockIdx.x * WG; base < n; base += (size_t)gridDim.x * WG) {
+    const size_t gid = base + threadIdx.x;
+    const bool active = gid < n;
+    const size_t idx = active ? gid : n - 1;
+    const uint8_t* __restrict__ k = scalars + idx * 32;
+    T qx, qy, qz, qt;  // the neutral element (0, 1, 1, 0)
+    u_set_zero(qx); u_set_zero(qy); u_set_zero(qz); u_set_zero(qt);
+    qy.v[0] = 1; qz.v[0] = 1;
+    for (int w = 0; w < 32; ++w) {
+      const uint32_t d = k[31 - w];  // big-endian scalar bytes (curve25519.rs:842-846)
+      const uint4* __restrict__ e4 = reinterpret_cast<const uint4*>(table + ((size_t)w * 256 + d) * ED_U_ENTRY_WORDS);
+      uint32_t ew[ED_U_ENTRY_WORDS];
+#pragma unroll
+      for (int i = 0; i < ED_U_ENTRY_WORDS / 4; ++i) {
+        const uint4 v = e4[i];
+        ew[4 * i] = v.x; ew[4 * i + 1] = v.y; ew[4 * i + 2] = v.z; ew[4 * i + 3] = v.w;
+      }
+      T ym, yp, t2d;
+#pragma unroll
+      for (int i = 0; i < N; ++i) { ym.v[i] = ew[i]; yp.v[i] = ew[N + i]; t2d.v[i] = ew[2 * N + i]; }
+      // Point::add with Z2 = 1 and the operand prepared in the table (curve25519.rs:695-729)
+      auto aa = u_mul(u_sub(qy, qx), ym);
+      auto bb = u_mul(u_add(qy, qx), yp);
+      auto cc = u_mul(qt, t2d);
+      auto dd = u_add(qz, qz);
+      auto e = u_sub(bb, aa);
+      auto f = u_reduce(u_sub(dd, cc));
+      auto g = u_add(dd, cc);
+      auto h = u_add(bb, aa);
+      qx = u_fit<1, 3>(u_mul(e, f));
+      qy = u_fit<1, 3>(u_mul(g, h));
+      qz = u_fit<1, 3>(u_mul(f, g));
+      qt = u_fit<1, 3>(u_mul(e, h));
+    }
+    if (active) {
+      Pt<CS> row;
+      u_to_canonical<CU>(row.x, qx);
+      u_to_canonical<CU>(row.y, qy);
+      u_to_canonical<CU>(row.z, qz);
       row_store<CS>(rows_out + idx * (size_t)row_words<L>(), row);
       flags[idx] = 0;
     }
