@@ -219,6 +219,18 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_var_uns
     }
     const uint8_t* __restrict__ k = scalars + idx * (size_t)SB;
 
+    // Booth digit of window w: |digit| in 0..16 and its sign (see k_scalarmul_var_fast)
+    auto booth = [&](int w, uint32_t& d, bool& neg) {
+      const int pos = 5 * w - 1 + 8;
+      const int bi = pos >> 3;
+      const uint32_t b0 = (bi >= 1 && bi <= SB) ? k[SB - bi] : 0u;
+      const uint32_t b1 = (bi + 1 <= SB) ? k[SB - bi - 1] : 0u;
+      const uint32_t w6 = ((b0 | (b1 << 8)) >> (pos & 7)) & 0x3fu;
+      const uint32_t s = ~((w6 >> 5) - 1u);
+      const uint32_t m = (((1u << 6) - w6 - 1u) & s) | (w6 & ~s);
+      d = (m >> 1) + (m & 1u);
+      neg = (s & 1u) != 0;
+    };
     int b = 0;                    // table-build step: 0 -> T[2] = 2P, 1..14 -> T[b+2] = T[b+1] + P
     int win = NWIN - 1, sub = 5;  // the top window needs no doublings
     bool fix_pending = false, fix_lane = false;
@@ -243,33 +255,35 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_var_uns
       } else {
         uint32_t d = 1;
         bool neg = false;
-        if (!building) {  // Booth digit of window `win` (see k_scalarmul_var_fast)
-          const int pos = 5 * win - 1 + 8;
-          const int bi = pos >> 3;
-          const uint32_t b0 = (bi >= 1 && bi <= SB) ? k[SB - bi] : 0u;
-          const uint32_t b1 = (bi + 1 <= SB) ? k[SB - bi - 1] : 0u;
-          const uint32_t w6 = ((b0 | (b1 << 8)) >> (pos & 7)) & 0x3fu;
-          const uint32_t s = ~((w6 >> 5) - 1u);
-          uint32_t m = (((1u << 6) - w6 - 1u) & s) | (w6 & ~s);
-          d = (m >> 1) + (m & 1u);
-          neg = (s & 1u) != 0;
-        }
+        if (!building) booth(win, d, neg);
         UEntry<CU> e;
         uentry_load<CU>(e, row(ECCX_EXP_ROW(d ? d : 1)));
         const bool q_inf = u_limbs_all_zero(q.z);
         const bool e_skip = (d == 0) || u_limbs_all_zero(e.z);
         UJac<CU> sum;
-        U<CU, 1, 3> ey;
         bool hz, rz;
-        ujac_add_raw<CU>(sum, hz, rz, ey, q, e, neg);
+        {
+          U<CU, 1, 3> ey;
+          ujac_add_raw<CU>(sum, hz, rz, ey, q, e, neg);
+        }
         const bool same_x = hz && !q_inf && !e_skip;
         fix_lane = same_x && rz;           // q == +-e with equal y: needs a doubling
         const bool to_inf = same_x && !rz; // opposite points
         if (to_inf) u_set_zero(sum.z);
-        // accumulator at infinity: the sum is the (signed) entry itself
-        u_select(sum.x, q_inf, e.x, sum.x);
-        u_select(sum.y, q_inf, ey, sum.y);
-        u_select(sum.z, q_inf, u_as<UJac<CU>::ZK, UJac<CU>::ZV>(e.z), sum.z);
+        // accumulator at infinity (the top window; afterwards only after a cancellation): the sum
+        // is the (signed) entry itself.  The entry is read again here rather than kept in
+        // registers across the addition -- that is what used to push the body into spilling.
+        if (__builtin_amdgcn_ballot_w64(q_inf) != 0) {
+          UEntry<CU> e2;
+          const uint32_t* again = row(ECCX_EXP_ROW(d ? d : 1));
+          asm volatile("" : "+v"(again));  // a fresh read: do not keep the first copy alive instead
+          uentry_load<CU>(e2, again);
+          U<CU, 2, 4> sy;
+          u_select(sy, neg, u_neg(e2.y), u_as<2, 4>(e2.y));
+          u_select(sum.x, q_inf, e2.x, sum.x);
+          u_select(sum.y, q_inf, u_reduce(sy), sum.y);
+          u_select(sum.z, q_inf, u_as<UJac<CU>::ZK, UJac<CU>::ZV>(e2.z), sum.z);
+        }
         const bool keep = e_skip || fix_lane;
         u_select(q.x, keep, q.x, sum.x);
         u_select(q.y, keep, q.y, sum.y);
