@@ -167,8 +167,11 @@ ECCX_DEV void uentry_load(UEntry<CU>& p, const uint32_t* __restrict__ row) {
 #ifndef ECCX_OCC_U14
 #define ECCX_OCC_U14 2
 #endif
+#ifndef ECCX_OCC_U18
+#define ECCX_OCC_U18 2
+#endif
 template <class CU>
-constexpr int unsat_occupancy() { return CU::N <= 9 ? 4 : (CU::N <= 14 ? ECCX_OCC_U14 : 2); }
+constexpr int unsat_occupancy() { return CU::N <= 9 ? 4 : (CU::N <= 14 ? ECCX_OCC_U14 : ECCX_OCC_U18); }
 
 template <class CU>
 __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_var_unsat(size_t n, const uint8_t* __restrict__ scalars,

@@ -37,6 +37,10 @@
 #pragma once
 #include "fe.hpp"
 
+#ifndef ECCX_SOLINAS_REDUCE
+#define ECCX_SOLINAS_REDUCE 1  // 0: A/B switch back to the generic signed 64-bit chain
+#endif
+
 namespace eccx {
 
 #include "umad_chunks.inc"
@@ -322,6 +326,28 @@ ECCX_DEV U<C, 1, 3> u_reduce(const U<C, K1, V1>& a) {
       c = t >> C::B;
     }
     r.v[N - 1] = a.v[N - 1] + c - (q << C::TOPSHIFT);
+  } else if constexpr (ECCX_SOLINAS_REDUCE && C::KIND == UK_MONT_PP1 && C::SOL_N > 0 && K1 < UB<C>::KMAX && V1 < 64) {
+    // Solinas prime: -q*p = q - q*(p+1), and p + 1 is a handful of powers of two, so q*p comes
+    // off as shifted copies of q -- no multiplications, 32-bit arithmetic.  Limbs that lose a
+    // copy are biased by 2^B, the bias being returned one limb higher (sum of the biases = 0),
+    // so no partial sum is negative; K1 < KMAX keeps "limb + 2^B + copies of q" below 2^32.
+    uint32_t c = q;
+#pragma unroll
+    for (int i = 0; i < N - 1; ++i) {
+      uint32_t t = a.v[i] + c;
+      if (i == C::SOL_BIAS_FROM) t += C::MASK + 1u;
+      if (i > C::SOL_BIAS_FROM) t += C::MASK;
+#pragma unroll
+      for (int j = 0; j < C::SOL_N; ++j) {
+        if (C::SOL_LIMB[j] == i) {
+          if (C::SOL_SIGN[j] > 0) t -= q << C::SOL_SHIFT[j];
+          else t += q << C::SOL_SHIFT[j];
+        }
+      }
+      r.v[i] = t & C::MASK;
+      c = t >> C::B;
+    }
+    r.v[N - 1] = a.v[N - 1] + c - (q << C::TOPSHIFT) - (C::SOL_BIAS_FROM < N - 1 ? 1u : 0u);
   } else {
     const int32_t nq = -(int32_t)q;
     int64_t acc = 0;

@@ -22,7 +22,7 @@ struct Chk {
 };
 
 enum : int { OP_MUL_TIGHT = 0, OP_MUL_LAZY = 1, OP_SQR_LAZY = 2, OP_SUB_CHAIN = 3, OP_REDUCE_MAX = 4,
-             OP_CANONICAL = 5, OP_MUL_AUTO = 6, OP_ADD_AUTO = 7 };
+             OP_CANONICAL = 5, OP_MUL_AUTO = 6, OP_ADD_AUTO = 7, OP_REDUCE_LAZY = 8 };
 
 template <class C, int K, int V>
 __device__ U<C, K, V> load_u(const uint32_t* p) {
@@ -76,6 +76,9 @@ __global__ void k_field_check(int op, const uint32_t* __restrict__ a, const uint
       store_u(po, u_reduce(u_add(u_add(x, y), u_add(x, y))));
       break;
     }
+    case OP_REDUCE_LAZY:  // the bounds under which the Solinas primes reduce with shifts of q
+      store_u(po, u_reduce(load_u<C, KM - 1, 48>(pa)));
+      break;
     default: break;
   }
 }

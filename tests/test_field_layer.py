@@ -27,7 +27,7 @@ P = {
     4: 2**255 - 19,
 }
 NAMES = {0: "p256r1", 1: "p384r1", 2: "p521r1", 3: "bls12_381_g1", 4: "curve25519"}
-OP_MUL_TIGHT, OP_MUL_LAZY, OP_SQR_LAZY, OP_SUB_CHAIN, OP_REDUCE_MAX, OP_CANONICAL, OP_MUL_AUTO, OP_ADD_AUTO = range(8)
+OP_MUL_TIGHT, OP_MUL_LAZY, OP_SQR_LAZY, OP_SUB_CHAIN, OP_REDUCE_MAX, OP_CANONICAL, OP_MUL_AUTO, OP_ADD_AUTO, OP_REDUCE_LAZY = range(9)
 
 
 class FieldCheck:
@@ -151,6 +151,12 @@ def test_sums_differences_and_reductions(fc, curve):
     a = gen(rng, inf, p, inf["KMAX"], 64, n)
     out = fc.run(curve, OP_REDUCE_MAX, a, a)
     for ra, ro in zip(a, out):
+        check_out(ro, inf, p, value(ra, inf["B"]), exact_digits=True)
+    # limbs one step below the 32-bit limit, value below 48p: the shift-and-add reduction of the
+    # Solinas primes (the other fields take their usual chain)
+    a2 = gen(rng, inf, p, inf["KMAX"] - 1, 48, n)
+    out = fc.run(curve, OP_REDUCE_LAZY, a2, a2)
+    for ra, ro in zip(a2, out):
         check_out(ro, inf, p, value(ra, inf["B"]), exact_digits=True)
     b = gen(rng, inf, p, inf["KMAX"], 64, n)
     rng.shuffle(b)

@@ -66,7 +66,7 @@ def digits(x, bits, n):
     return [(x >> (bits * i)) & ((1 << bits) - 1) for i in range(n)]
 
 
-def emit_unsat(out, name, sat_name, p, gx, gy, bits, n, kind, extra=()):
+def emit_unsat(out, name, sat_name, p, gx, gy, bits, n, kind, extra=(), solinas=()):
     """Constants of the unsaturated representation: n limbs of `bits` bits in 32-bit registers.
     kind 0: Montgomery, R = 2^(bits*n), p = -1 mod 2^bits (reduce with the digits of p + 1)
     kind 1: Montgomery, general p (m = acc * N0B mod 2^bits)
@@ -114,6 +114,20 @@ def emit_unsat(out, name, sat_name, p, gx, gy, bits, n, kind, extra=()):
     out.append(arr("ONE", digits(R % p, bits, n)))
     out.append(arr("R2", digits(R * R % p, bits, n)))
     out.append(arr("BIAS", bias))
+    # Solinas form p + 1 = 2^PBITS + sum(sign * 2^e): lets the weak reduction take off q*p with
+    # shifts of q instead of multiplications (kind 0 only); terms as (limb, shift, sign)
+    if solinas:
+        assert (1 << pbits) + sum(sg << e for e, sg in solinas) == p + 1
+        terms = [(e // bits, e % bits, sg) for e, sg in solinas]
+        assert all(l < n - 1 for l, _, _ in terms)
+        pos = [l for l, _, sg in terms if sg > 0]   # a positive term is subtracted: may borrow
+        out.append("  static constexpr int SOL_N = %d;" % len(terms))
+        out.append("  static constexpr int SOL_LIMB[%d] = {%s};" % (len(terms), ", ".join(str(t[0]) for t in terms)))
+        out.append("  static constexpr int SOL_SHIFT[%d] = {%s};" % (len(terms), ", ".join(str(t[1]) for t in terms)))
+        out.append("  static constexpr int SOL_SIGN[%d] = {%s};" % (len(terms), ", ".join(str(t[2]) for t in terms)))
+        out.append("  static constexpr int SOL_BIAS_FROM = %d;  // lowest limb a subtraction touches" % (min(pos) if pos else n))
+    else:
+        out.append("  static constexpr int SOL_N = 0;")
     out.append(arr("GX", digits(gx * R % p, bits, n)))
     out.append(arr("GY", digits(gy * R % p, bits, n)))
     for cname, val in extra:
@@ -139,8 +153,10 @@ def main():
         out.append(arr("GY", limbs(gy * R % p, L)))
         out.append("};")
         out.append("")
-    emit_unsat(out, "P256U", "P256", CURVES[0][1], CURVES[0][3], CURVES[0][4], 29, 9, 0)
-    emit_unsat(out, "P384U", "P384", CURVES[1][1], CURVES[1][3], CURVES[1][4], 28, 14, 0)
+    emit_unsat(out, "P256U", "P256", CURVES[0][1], CURVES[0][3], CURVES[0][4], 29, 9, 0,
+               solinas=((224, -1), (192, 1), (96, 1)))
+    emit_unsat(out, "P384U", "P384", CURVES[1][1], CURVES[1][3], CURVES[1][4], 28, 14, 0,
+               solinas=((128, -1), (96, -1), (32, 1)))
     emit_unsat(out, "P521U", "P521", CURVES[2][1], CURVES[2][3], CURVES[2][4], 29, 18, 2)
     emit_unsat(out, "BLS12_381U", "BLS12_381", CURVES[3][1], CURVES[3][3], CURVES[3][4], 28, 14, 1)
     L = 8
