@@ -46,7 +46,8 @@ def _sat(muls, pairs_per_mul):
 def _var_unsat(n, nz, sb, a0, inv, sat_pairs, mont=True):
     """default variable-base path (kernels_unsat.hpp): n limbs of 28/29 bits, one
     v_mad_u64_u32 per limb product.  A product is n*n + n*nz mads (nz = non-zero reduction
-    digits per Montgomery factor: those of p + 1 for the NIST primes, all n for BLS12-381,
+    digits per Montgomery factor: those of p + 1 for P-256, the 4 signed terms of p + 1 for
+    P-384, all n for BLS12-381,
     none for the Mersenne prime whose wrapped half shares the columns), a square n(n+1)/2 +
     n*nz.  Doubling = 4 products + 4 squares (a = -3) or 2 + 5 (a = 0), addition = 11 + 3;
     ceil((8*sb + 1)/5) signed windows; the normalisation kernel stays saturated."""
@@ -74,7 +75,7 @@ WORKLOADS = {
     # unsaturated 9 x 29 ladder: per bit 5 products (81 + 9 mads), 4 squares (45 + 9), one small multiple (9 + 1)
     "x25519_2^20": ("ed25519", "x25519", 1 << 20, 96,
                     {"mad": 256 * (5 * 90 + 4 * 54 + 10), "pair": ((380 + 15) // 16 + 6) * (8 * 8 + 8)}),
-    "p384r1_var_2^19": ("p384r1", "var", 1 << 19, 240, _var_unsat(14, 12, 48, 0, 575, 12 * 12 + 12 * 10)),
+    "p384r1_var_2^19": ("p384r1", "var", 1 << 19, 240, _var_unsat(14, 4, 48, 0, 575, 12 * 12 + 12 * 10)),
     "p521r1_var_2^19": ("p521r1", "var", 1 << 19, 330, _var_unsat(18, 0, 66, 0, 780, 17 * 17, mont=False)),
     "bls12_381_g1_var_2^20": ("bls12_381_g1", "var", 1 << 20, 224, _var_unsat(14, 14, 32, 1, 570, 2 * 12 * 12)),
 }

@@ -45,6 +45,11 @@ namespace eccx {
 
 #include "umad_chunks.inc"
 
+// acc += a * k for a NEGATIVE constant k (signed columns of the sparse reduction)
+__device__ __forceinline__ void smad1_k(uint64_t& acc, uint32_t a, int32_t k) {
+  asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "s"(k) : "vcc");
+}
+
 enum : int { UK_MONT_PP1 = 0, UK_MONT = 1, UK_MERSENNE = 2, UK_PM19 = 3 };
 
 template <class C, int K, int V>
@@ -64,8 +69,11 @@ struct UB {
   // largest K1*K2 a product may have: Montgomery columns hold N products + N reduction
   // products; the Mersenne columns hold N direct products + N - 1 doubled wrapped ones
   // (kind 3: N products + one folded digit times 1216)
-  static constexpr int KKMAX = !WRAPPED ? (int)(~(uint64_t)0 / ((uint64_t)C::N * COL)) - 1
-                                        : (int)(~(uint64_t)0 / ((uint64_t)(2 * C::N - 1) * COL));
+  // (sparse reduction: the columns are signed, one bit less)
+  static constexpr bool SPARSE = C::KIND == UK_MONT_PP1 && C::SPARSE_N > 0;
+  static constexpr int KKMAX = WRAPPED  ? (int)(~(uint64_t)0 / ((uint64_t)(2 * C::N - 1) * COL))
+                               : SPARSE ? (int)((~(uint64_t)0 >> 1) / ((uint64_t)C::N * COL)) - 1
+                                        : (int)(~(uint64_t)0 / ((uint64_t)C::N * COL)) - 1;
   static_assert(KKMAX >= 1, "limbs too wide for this many columns");
   static constexpr bool kk_ok(int k1, int k2) { return k1 * k2 <= KKMAX; }
   // squares also shift the operand left by one (two for the wrapped cross terms)
@@ -152,11 +160,30 @@ ECCX_DEV void u_mul_core_mont(uint32_t (&r)[C::N], const uint32_t (&a)[C::N], co
       for (int i = lo; i <= hi; ++i) qa.push(acc, a[i], b[k - i]);
     }
     qa.flush(acc);
+    if constexpr (UB<C>::SPARSE) {
+      // m*(p+1) as signed shifted copies of m: term t lands in column i + OFF[t]
 #pragma unroll
-    for (int i = lo; i <= (k < N ? k - 1 : N - 1); ++i) {
-      if (PR(k - i) != 0) qm.push(acc, m[i], PR(k - i));
+      for (int t = 0; t < C::SPARSE_N; ++t) {
+        const int i = k - C::SPARSE_OFF[t];
+        if (i >= lo && i <= (k < N ? k - 1 : N - 1)) {
+          if (C::SPARSE_SIGN[t] > 0) qm.push(acc, m[i], 1u << C::SPARSE_SHIFT[t]);
+        }
+      }
+      qm.flush(acc);
+#pragma unroll
+      for (int t = 0; t < C::SPARSE_N; ++t) {
+        const int i = k - C::SPARSE_OFF[t];
+        if (i >= lo && i <= (k < N ? k - 1 : N - 1)) {
+          if (C::SPARSE_SIGN[t] < 0) smad1_k(acc, m[i], -(int32_t)(1u << C::SPARSE_SHIFT[t]));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = lo; i <= (k < N ? k - 1 : N - 1); ++i) {
+        if (PR(k - i) != 0) qm.push(acc, m[i], PR(k - i));
+      }
+      qm.flush(acc);
     }
-    qm.flush(acc);
     if (k < N) {
       if constexpr (PP1) {
         // -p^-1 mod 2^B = 1, so m[k] is the low limb itself, and m*p = m*(p+1) - m: the "- m"
@@ -169,7 +196,8 @@ ECCX_DEV void u_mul_core_mont(uint32_t (&r)[C::N], const uint32_t (&a)[C::N], co
     } else {
       t[k - N] = (uint32_t)acc & C::MASK;
     }
-    acc >>= C::B;
+    if constexpr (UB<C>::SPARSE) acc = (uint64_t)((int64_t)acc >> C::B);  // columns may be negative
+    else acc >>= C::B;
   }
   t[N - 1] = (uint32_t)acc;
 #pragma unroll

@@ -66,7 +66,7 @@ def digits(x, bits, n):
     return [(x >> (bits * i)) & ((1 << bits) - 1) for i in range(n)]
 
 
-def emit_unsat(out, name, sat_name, p, gx, gy, bits, n, kind, extra=(), solinas=()):
+def emit_unsat(out, name, sat_name, p, gx, gy, bits, n, kind, extra=(), solinas=(), sparse=False):
     """Constants of the unsaturated representation: n limbs of `bits` bits in 32-bit registers.
     kind 0: Montgomery, R = 2^(bits*n), p = -1 mod 2^bits (reduce with the digits of p + 1)
     kind 1: Montgomery, general p (m = acc * N0B mod 2^bits)
@@ -128,6 +128,18 @@ def emit_unsat(out, name, sat_name, p, gx, gy, bits, n, kind, extra=(), solinas=
         out.append("  static constexpr int SOL_BIAS_FROM = %d;  // lowest limb a subtraction touches" % (min(pos) if pos else n))
     else:
         out.append("  static constexpr int SOL_N = 0;")
+    # sparse Montgomery reduction: m*(p+1) added as signed shifted copies of m, one per term of
+    # p + 1 (column offset, shift inside the column, sign) instead of one product per non-zero
+    # digit -- pays when p + 1 has long runs of ones (P-384: 4 terms against 12 digits)
+    if sparse:
+        allterms = [(pbits, 1)] + list(solinas)
+        out.append("  static constexpr int SPARSE_N = %d;" % len(allterms))
+        out.append("  static constexpr int SPARSE_OFF[%d] = {%s};" % (len(allterms), ", ".join(str(e // bits) for e, _ in allterms)))
+        out.append("  static constexpr int SPARSE_SHIFT[%d] = {%s};" % (len(allterms), ", ".join(str(e % bits) for e, _ in allterms)))
+        out.append("  static constexpr int SPARSE_SIGN[%d] = {%s};" % (len(allterms), ", ".join(str(sg) for _, sg in allterms)))
+        assert all(0 < e // bits < n for e, _ in allterms)
+    else:
+        out.append("  static constexpr int SPARSE_N = 0;")
     out.append(arr("GX", digits(gx * R % p, bits, n)))
     out.append(arr("GY", digits(gy * R % p, bits, n)))
     for cname, val in extra:
@@ -156,7 +168,7 @@ def main():
     emit_unsat(out, "P256U", "P256", CURVES[0][1], CURVES[0][3], CURVES[0][4], 29, 9, 0,
                solinas=((224, -1), (192, 1), (96, 1)))
     emit_unsat(out, "P384U", "P384", CURVES[1][1], CURVES[1][3], CURVES[1][4], 28, 14, 0,
-               solinas=((128, -1), (96, -1), (32, 1)))
+               solinas=((128, -1), (96, -1), (32, 1)), sparse=True)
     emit_unsat(out, "P521U", "P521", CURVES[2][1], CURVES[2][3], CURVES[2][4], 29, 18, 2)
     emit_unsat(out, "BLS12_381U", "BLS12_381", CURVES[3][1], CURVES[3][3], CURVES[3][4], 28, 14, 1)
     L = 8
