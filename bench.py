@@ -75,6 +75,11 @@ WORKLOADS = {
     # unsaturated 9 x 29 ladder: per bit 5 products (81 + 9 mads), 4 squares (45 + 9), one small multiple (9 + 1)
     "x25519_2^20": ("ed25519", "x25519", 1 << 20, 96,
                     {"mad": 256 * (5 * 90 + 4 * 54 + 10), "pair": ((380 + 15) // 16 + 6) * (8 * 8 + 8)}),
+    # edwards25519 variable base: 52 signed windows of 4 x (4 squares + 3 products) + (4 + 4) + a
+    # 7-product addition; table of 16 cached multiples (1 doubling, 14 additions of 8, 16 x 2d*T)
+    "ed25519_var_2^20": ("ed25519", "var", 1 << 20, 160,
+                         {"mad": (51 * 20 + 4) * 54 + (51 * 16 + 52 * 7 + 4 + 14 * 8 + 16 + 1) * 90,
+                          "pair": ((380 + 15) // 16 + 7) * (8 * 8 + 8)}),
     "p384r1_var_2^19": ("p384r1", "var", 1 << 19, 240, _var_unsat(14, 4, 48, 0, 575, 12 * 12 + 12 * 10)),
     "p521r1_var_2^19": ("p521r1", "var", 1 << 19, 330, _var_unsat(18, 0, 66, 0, 780, 17 * 17, mont=False)),
     "bls12_381_g1_var_2^20": ("bls12_381_g1", "var", 1 << 20, 224, _var_unsat(14, 14, 32, 1, 570, 2 * 12 * 12)),

@@ -39,6 +39,15 @@ hipError_t base_w8_(int grid, hipStream_t s, size_t n, const uint8_t* scalars, c
   hipLaunchKernelGGL(k_ed_scalarmul_base_unsat<ED25519U>, dim3(grid), dim3(WG), 0, s, n, scalars, table, rows, flags);
   return hipGetLastError();
 }
+hipError_t var_fast_(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint8_t* points, uint32_t* rows,
+                     uint8_t* flags, uint32_t* scratch, uint32_t opts) {
+  hipLaunchKernelGGL(k_ed_scalarmul_var_unsat<ED25519U>, dim3(grid), dim3(WG), 0, s, n, scalars, points, rows, flags, scratch, opts);
+  return hipGetLastError();
+}
+int var_fast_grid_(int cus, size_t n) {
+  static const int occ = occupancy_per_cu(k_ed_scalarmul_var_unsat<ED25519U>);
+  return persistent_grid(occ, cus, n);
+}
 int var_grid_(int cus, size_t n) {
   static const int occ = occupancy_per_cu(k_ed_scalarmul_var<ED25519>);
   return persistent_grid(occ, cus, n);
@@ -60,7 +69,7 @@ hipError_t launch_x25519_to_u(int grid, hipStream_t s, size_t n, const uint32_t*
   return hipGetLastError();
 }
 const CurveOps& ops_ED25519() {
-  static const CurveOps o = {{ED25519::FB, ED25519::SB, ED25519::L, 4 * ED25519::L, 0, 1, 0, row_words<ED25519::L>()}, var_, base_, nullptr, nullptr, nullptr, base_lds_, to_affine_hom_, var_grid_, nullptr, to_affine_hom_, point_add_, ED_U_ENTRY_WORDS, comb_convert_, base_w8_};
+  static const CurveOps o = {{ED25519::FB, ED25519::SB, ED25519::L, 4 * ED25519::L, 0, 1, ED_VAR_ROW_WORDS, row_words<ED25519::L>()}, var_, base_, var_fast_, nullptr, nullptr, base_lds_, to_affine_hom_, var_grid_, var_fast_grid_, to_affine_hom_, point_add_, ED_U_ENTRY_WORDS, comb_convert_, base_w8_};
   return o;
 }
 }  // namespace eccx

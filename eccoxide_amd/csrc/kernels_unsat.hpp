@@ -623,4 +623,214 @@ __global__ void __launch_bounds__(WG, 4) k_ed_scalarmul_base_unsat(size_t n, con
   }
 }
 
+// ---- edwards25519 variable base, signed 5-bit windows, unsaturated field ---------------------
+// The reference's Point::scale (src/curve/curve25519.rs:746-762) is a 256-step double-and-add
+// with the unified addition (:695-710).  k*P does not depend on the addition chain, so the
+// default path uses the same signed 5-bit windows as the Weierstrass ladder: table d*P,
+// d = 0..16, in a per-lane HBM slab as (Y - X, Y + X, 2Z, 2d*T); 52 windows of 5 doublings +
+// 1 addition.  The a = -1 twisted Edwards formulas are complete on this curve (d is not a
+// square), so there are no special cases at all: digit 0 adds the neutral entry, a negative
+// digit swaps Y - X with Y + X and negates 2d*T.  Doubling: 4 squares + 3 products (+ 1 for T
+// when an addition follows); addition: 8 products (7 in the main loop, where T is not needed).
+template <class CU>
+struct UEd {
+  U<CU, 1, 3> x, y, z, t;
+};
+template <class CU>
+struct UEdCached {
+  U<CU, 1, 3> ym, yp, z2, t2d;
+};
+constexpr int ED_VAR_ROW_WORDS = 36;  // 4 x 9 digits
+
+template <class CU, bool WITH_T>
+ECCX_DEV void ued_dbl(UEd<CU>& r, const UEd<CU>& p) {
+  auto a = u_sqr(p.x);
+  auto b = u_sqr(p.y);
+  auto zz = u_sqr(p.z);
+  auto xy = u_sqr(u_add(p.x, p.y));
+  auto e = u_reduce(u_sub(u_sub(xy, a), b));      // E = (X+Y)^2 - A - B
+  auto g = u_reduce(u_sub(b, a));                 // G = D + B = B - A      (D = -A)
+  auto f = u_reduce(u_sub(u_sub(g, zz), zz));     // F = G - 2 Z^2
+  auto h = u_sub(u_neg(a), b);                    // H = D - B = -(A + B)
+  r.x = u_fit<1, 3>(u_mul(e, f));
+  r.y = u_fit<1, 3>(u_mul(g, h));
+  r.z = u_fit<1, 3>(u_mul(f, g));
+  if constexpr (WITH_T) r.t = u_fit<1, 3>(u_mul(e, h));
+}
+
+template <class CU, bool WITH_T>
+ECCX_DEV void ued_add(UEd<CU>& r, const UEd<CU>& p, const UEdCached<CU>& c, bool neg) {
+  U<CU, 1, 3> ym, yp;
+  u_select(ym, neg, c.yp, c.ym);
+  u_select(yp, neg, c.ym, c.yp);
+  auto aa = u_mul(u_sub(p.y, p.x), ym);
+  auto bb = u_mul(u_add(p.y, p.x), yp);
+  auto cc = u_mul(p.t, c.t2d);                    // sign applied below: C -> -C swaps F and G
+  auto dd = u_mul(p.z, c.z2);
+  auto e = u_sub(bb, aa);
+  auto h = u_add(bb, aa);
+  auto dmc = u_fit<3, 8>(u_sub(dd, cc));
+  auto dpc = u_fit<3, 8>(u_add(dd, cc));
+  U<CU, 3, 8> fl, g;
+  u_select(fl, neg, dpc, dmc);                    // F = D - C
+  u_select(g, neg, dmc, dpc);                     // G = D + C
+  auto f = u_reduce(fl);
+  r.x = u_fit<1, 3>(u_mul(e, f));
+  r.y = u_fit<1, 3>(u_mul(g, h));
+  r.z = u_fit<1, 3>(u_mul(f, g));
+  if constexpr (WITH_T) r.t = u_fit<1, 3>(u_mul(e, h));
+}
+
+template <class CU>
+ECCX_DEV void ued_cache(UEdCached<CU>& c, const UEd<CU>& p) {
+  U<CU, 1, 2> d2;
+#pragma unroll
+  for (int k = 0; k < CU::N; ++k) d2.v[k] = CU::D2[k];
+  c.ym = u_reduce(u_sub(p.y, p.x));
+  c.yp = u_reduce(u_add(p.y, p.x));
+  c.z2 = u_reduce(u_add(p.z, p.z));
+  c.t2d = u_fit<1, 3>(u_mul(p.t, d2));
+}
+
+template <class CU>
+ECCX_DEV void ued_row_store(uint32_t* __restrict__ row, const UEdCached<CU>& c) {
+  constexpr int N = CU::N;
+  static_assert(4 * N == ED_VAR_ROW_WORDS, "row layout");
+  uint32_t w[ED_VAR_ROW_WORDS];
+#pragma unroll
+  for (int i = 0; i < N; ++i) { w[i] = c.ym.v[i]; w[N + i] = c.yp.v[i]; w[2 * N + i] = c.z2.v[i]; w[3 * N + i] = c.t2d.v[i]; }
+  uint4* dst = reinterpret_cast<uint4*>(row);
+#pragma unroll
+  for (int i = 0; i < ED_VAR_ROW_WORDS / 4; ++i) dst[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+template <class CU>
+ECCX_DEV void ued_row_load(UEdCached<CU>& c, const uint32_t* __restrict__ row) {
+  constexpr int N = CU::N;
+  uint32_t w[ED_VAR_ROW_WORDS];
+  const uint4* src = reinterpret_cast<const uint4*>(row);
+#pragma unroll
+  for (int i = 0; i < ED_VAR_ROW_WORDS / 4; ++i) {
+    const uint4 q = src[i];
+    w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) { c.ym.v[i] = w[i]; c.yp.v[i] = w[N + i]; c.z2.v[i] = w[2 * N + i]; c.t2d.v[i] = w[3 * N + i]; }
+}
+
+template <class CU>
+__global__ void __launch_bounds__(WG, 4) k_ed_scalarmul_var_unsat(size_t n, const uint8_t* __restrict__ scalars,
+                                                                  const uint8_t* __restrict__ points,
+                                                                  uint32_t* __restrict__ rows_out, uint8_t* __restrict__ flags,
+                                                                  uint32_t* __restrict__ scratch, uint32_t opts) {
+  using CS = typename CU::Sat;
+  constexpr int L = CS::L;
+  constexpr int N = CU::N;
+  constexpr int NWIN = (8 * 32 + 1 + 4) / 5;
+  constexpr int RW = ED_VAR_ROW_WORDS;
+  uint32_t* slab = scratch + ((size_t)blockIdx.x * FAST_TABLE_ROWS * WG + threadIdx.x) * (size_t)RW;
+  auto row = [&](uint32_t e) { return slab + (size_t)e * WG * RW; };
+  for (size_t base = (size_t)blockIdx.x * WG; base < n; base += (size_t)gridDim.x * WG) {
+    const size_t gid = base + threadIdx.x;
+    const bool active = gid < n;
+    const size_t idx = active ? gid : n - 1;
+    UEd<CU> p;
+    bool rejected = false;
+    if (opts & OPT_BASE_IS_GENERATOR) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) { p.x.v[i] = CU::GX[i]; p.y.v[i] = CU::GY[i]; }
+    } else {
+      Fe<L> rx, ry;
+      fe_load_le<CS>(rx, points + idx * 64);
+      fe_load_le<CS>(ry, points + idx * 64 + 32);
+      if (opts & OPT_VALIDATE) {
+        // -x^2 + y^2 == 1 + d x^2 y^2  <=>  2(y^2 - x^2 - 1) == 2d x^2 y^2  (curve25519.rs:649-660),
+        // on the saturated twin
+        Fe<L> mx, my, xx, yy, lhs, rhs, one;
+        fe_to_mont<CS>(mx, rx);
+        fe_to_mont<CS>(my, ry);
+        fe_sqr<CS>(xx, mx);
+        fe_sqr<CS>(yy, my);
+        fe_set<CS>(one, CS::ONE);
+        fe_sub<CS>(lhs, yy, xx);
+        fe_sub<CS>(lhs, lhs, one);
+        fe_add<CS>(lhs, lhs, lhs);
+        fe_mul<CS>(rhs, xx, yy);
+        fe_mul_k<CS>(rhs, rhs, CS::D2);
+        rejected = !(fe_is_canonical<CS>(rx) && fe_is_canonical<CS>(ry) && fe_eq<CS>(lhs, rhs));
+      }
+      p.x = u_reduce(u_as<1, 3>(u_from_sat<CU>(rx)));
+      p.y = u_reduce(u_as<1, 3>(u_from_sat<CU>(ry)));
+    }
+    u_set_zero(p.z);
+    p.z.v[0] = 1;
+    p.t = u_fit<1, 3>(u_mul(p.x, p.y));  // from_affine (curve25519.rs:638-645)
+    UEdCached<CU> c1;
+    ued_cache<CU>(c1, p);
+    ued_row_store<CU>(row(1), c1);
+    {
+      UEdCached<CU> c0;  // the neutral element (0, 1, 1, 0): (1, 1, 2, 0)
+      u_set_zero(c0.ym); u_set_zero(c0.yp); u_set_zero(c0.z2); u_set_zero(c0.t2d);
+      c0.ym.v[0] = 1; c0.yp.v[0] = 1; c0.z2.v[0] = 2;
+      ued_row_store<CU>(row(0), c0);
+    }
+    // table: T[2] = 2P, T[d+1] = T[d] + P
+    UEd<CU> q;
+    ued_dbl<CU, true>(q, p);
+    for (int d = 2; d <= 16; ++d) {
+      UEdCached<CU> c;
+      ued_cache<CU>(c, q);
+      ued_row_store<CU>(row(d), c);
+      if (d < 16) {
+        UEd<CU> s;
+        ued_add<CU, true>(s, q, c1, false);
+        q = s;
+      }
+    }
+    const uint8_t* __restrict__ k = scalars + idx * 32;
+    // Booth digit of window w: |digit| in 0..16 and its sign (big-endian scalar bytes)
+    auto booth = [&](int w, uint32_t& d, bool& neg) {
+      const int pos = 5 * w - 1 + 8;
+      const int bi = pos >> 3;
+      const uint32_t b0 = (bi >= 1 && bi <= 32) ? k[32 - bi] : 0u;
+      const uint32_t b1 = (bi + 1 <= 32) ? k[32 - bi - 1] : 0u;
+      const uint32_t w6 = ((b0 | (b1 << 8)) >> (pos & 7)) & 0x3fu;
+      const uint32_t s = ~((w6 >> 5) - 1u);
+      const uint32_t m = (((1u << 6) - w6 - 1u) & s) | (w6 & ~s);
+      d = (m >> 1) + (m & 1u);
+      neg = (s & 1u) != 0;
+    };
+    // the neutral element
+    u_set_zero(q.x); u_set_zero(q.y); u_set_zero(q.z); u_set_zero(q.t);
+    q.y.v[0] = 1; q.z.v[0] = 1;
+    for (int win = NWIN - 1; win >= 0; --win) {
+      if (win != NWIN - 1) {
+        for (int j = 0; j < 4; ++j) {
+          UEd<CU> s;
+          ued_dbl<CU, false>(s, q);
+          q.x = s.x; q.y = s.y; q.z = s.z;
+        }
+        UEd<CU> s;
+        ued_dbl<CU, true>(s, q);
+        q = s;
+      }
+      uint32_t d;
+      bool neg;
+      booth(win, d, neg);
+      UEdCached<CU> c;
+      ued_row_load<CU>(c, row(d));
+      UEd<CU> s;
+      ued_add<CU, false>(s, q, c, neg);
+      q.x = s.x; q.y = s.y; q.z = s.z;
+    }
+    if (active) {
+      Pt<CS> res;
+      u_to_canonical<CU>(res.x, q.x);
+      u_to_canonical<CU>(res.y, q.y);
+      u_to_canonical<CU>(res.z, q.z);
+      row_store<CS>(rows_out + idx * (size_t)row_words<L>(), res);
+      flags[idx] = rejected ? 2 : 0;
+    }
+  }
+}
+
 }  // namespace eccx

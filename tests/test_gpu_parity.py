@@ -162,6 +162,47 @@ def test_fast_ladder_small_order_point_bls(engine, oracle):
     assert set(want[1]) <= {0, 1} and 1 in set(want[1])   # k = 0 mod 3 gives infinity
 
 
+def _ed25519_points_outside_the_subgroup(count):
+    """curve points (x, y) lifted from small y values: 7 in 8 of them carry an 8-torsion part"""
+    p = 2**255 - 19
+    d = (-121665 * pow(121666, -1, p)) % p
+    out, y = [], 2
+    while len(out) < count:
+        y += 1
+        xx = (y * y - 1) * pow(d * y * y + 1, -1, p) % p
+        x = pow(xx, (p + 3) // 8, p)
+        if (x * x - xx) % p:
+            x = x * pow(2, (p - 1) // 4, p) % p
+        if (x * x - xx) % p == 0:
+            out.append((x, y))
+    return out
+
+
+def test_edwards_window_ladder_on_torsion_points(engine, oracle):
+    """The windowed Edwards ladder relies on the unified formulas being complete: run it on
+    points of order 1, 2, 4, 8 and on points of order 8*l, with edge and random scalars, against
+    the reference's double-and-add (mirror kernel and oracle)."""
+    order = W.order("ed25519")
+    pts = _ed25519_points_outside_the_subgroup(24)
+    le = lambda v: v.to_bytes(32, "little")
+    mixed = b"".join(le(x) + le(y) for x, y in pts)
+    # l * P leaves the torsion part: points of order dividing 8
+    tors, fl = oracle.var("ed25519", order.to_bytes(32, "big") * len(pts), mixed)[:2]
+    p = 2**255 - 19
+    special = le(0) + le(1) + le(0) + le(p - 1)          # the neutral element and the point of order 2
+    cases = mixed + tors + special
+    n = len(cases) // 64
+    rnd = W.random_scalars("ed25519", n, seed=77).tobytes()
+    edge = [0, 1, 2, 7, 8, 9, 16, 31, 32, order - 1, order, order + 1, 8 * order, (1 << 256) - 1, 1 << 255]
+    for ks in (rnd, b"".join(edge[i % len(edge)].to_bytes(32, "big") for i in range(n))):
+        want = oracle.var("ed25519", ks, cases)
+        got = engine.scalarmul_var("ed25519", ks, cases)
+        assert got[0] == want[0] and got[1] == want[1]
+        got = engine.scalarmul_var("ed25519", ks, cases, mirror=True)
+        assert got[0] == want[0] and got[1] == want[1]
+    assert len(set(tors[i:i + 64] for i in range(0, len(tors), 64))) >= 4  # several distinct torsion points
+
+
 # ---- the reference's own known-answer vectors, on the GPU ---------------------------------
 @pytest.mark.parametrize("curve", ["p256r1", "p384r1", "p521r1"])
 def test_nist_kg_on_gpu(engine, oracle, curve):
