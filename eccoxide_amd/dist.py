@@ -52,6 +52,53 @@ def gather_to_root(local: torch.Tensor, sizes, root: int = 0, group=None) -> Opt
     return None
 
 
+class GatherPipeline:
+    """Gather of equal result shards to the root, overlapped with the next batch.
+
+    The root pre-allocates `slots` receive areas (world x shard each) once; `start(slot, out,
+    flags)` enqueues the two gathers of one batch asynchronously -- on RCCL they run on the
+    communicator's own stream, each peer sending over its own xGMI link -- and `finish(slot)`
+    makes the caller's stream wait for them.  With two slots batch i+1 computes (into the other
+    pair of output buffers) while batch i is on the wire; a slot must be finished before its
+    source buffers are written again.  Results land contiguously (no concatenation copy):
+    `result(slot)` returns (out, flags) views on the root, (None, None) elsewhere.
+    """
+
+    def __init__(self, shard_rows: int, out_cols: int, device, slots: int = 2, root: int = 0, group=None):
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.root, self.group, self.rows = root, group, shard_rows
+        self.pending = [[] for _ in range(slots)]
+        self.local = [None] * slots
+        self.out = self.flags = None
+        if self.world > 1 and self.rank == root:
+            self.out = [torch.empty((self.world * shard_rows, out_cols), dtype=torch.uint8, device=device)
+                        for _ in range(slots)]
+            self.flags = [torch.empty((self.world * shard_rows,), dtype=torch.uint8, device=device)
+                          for _ in range(slots)]
+
+    def start(self, slot: int, out: torch.Tensor, flags: torch.Tensor) -> None:
+        assert not self.pending[slot], "slot still in flight: call finish(slot) first"
+        self.local[slot] = (out, flags)
+        if self.world == 1:
+            return
+        for src, dst in ((out, self.out), (flags, self.flags)):
+            bufs = list(dst[slot].split(self.rows, dim=0)) if self.rank == self.root else None
+            self.pending[slot].append(dist.gather(src, bufs, dst=self.root, group=self.group, async_op=True))
+
+    def finish(self, slot: int) -> None:
+        for w in self.pending[slot]:
+            w.wait()
+        self.pending[slot] = []
+
+    def result(self, slot: int):
+        if self.world == 1:
+            return self.local[slot]
+        if self.rank != self.root:
+            return None, None
+        return self.out[slot], self.flags[slot]
+
+
 def sharded_scalarmul(compute: Callable[[torch.Tensor, Optional[torch.Tensor]], Tuple[torch.Tensor, torch.Tensor]],
                       scalars: torch.Tensor, points: Optional[torch.Tensor], *, gather: bool = True, root: int = 0,
                       group=None):

@@ -68,3 +68,62 @@ def test_world2_sharded_matches_single(n):
         assert p.exitcode == 0
     root = [r for r in res if r[0] != "nonroot"][0]
     assert root[0] is True and root[1] is True and root[2] == (n, 64)
+
+
+def _pipeline_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from eccoxide_amd.dist import GatherPipeline
+
+        rows, cols, steps = 33, 8, 5
+        pipe = GatherPipeline(rows, cols, torch.device("cpu"), slots=2)
+        outs = [torch.empty((rows, cols), dtype=torch.uint8) for _ in range(2)]
+        flags = [torch.empty((rows,), dtype=torch.uint8) for _ in range(2)]
+
+        def batch(step, r):  # what rank r produces at this step
+            g = torch.Generator().manual_seed(1000 * step + r)
+            return (torch.randint(0, 256, (rows, cols), dtype=torch.uint8, generator=g),
+                    torch.randint(0, 3, (rows,), dtype=torch.uint8, generator=g))
+
+        ok = True
+        for i in range(steps):
+            slot = i & 1
+            pipe.finish(slot)
+            if rank == 0 and i >= 2:  # the batch that used this slot two steps ago is complete and intact
+                o, f = pipe.result(slot)
+                want = [batch(i - 2, r) for r in range(world)]
+                ok &= torch.equal(o, torch.cat([w[0] for w in want])) and torch.equal(f, torch.cat([w[1] for w in want]))
+            o, f = batch(i, rank)
+            outs[slot].copy_(o)
+            flags[slot].copy_(f)
+            pipe.start(slot, outs[slot], flags[slot])
+        pipe.finish(0)
+        pipe.finish(1)
+        if rank == 0:
+            for i in (steps - 2, steps - 1):
+                o, f = pipe.result(i & 1)
+                want = [batch(i, r) for r in range(world)]
+                ok &= torch.equal(o, torch.cat([w[0] for w in want])) and torch.equal(f, torch.cat([w[1] for w in want]))
+        else:
+            ok &= pipe.result(0) == (None, None)
+        q.put(bool(ok))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_gather_pipeline_overlaps_batches():
+    """bench.py's N > 1 loop: two slots, gather of batch i in flight while batch i+1 is produced."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [True, True]
