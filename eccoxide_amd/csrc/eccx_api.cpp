@@ -514,6 +514,26 @@ int eccx_double_scalarmul(eccx_ctx* ctx, int curve, size_t n, const uint8_t* u1,
   for (int i = 0; i < 3; ++i)
     if ((e = hipMemcpyAsync(d[i], src[i], sizes[i], hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
       return fail(e, "hipMemcpyAsync");
+  if (ops->var_fused && ops->to_affine_var) {
+    // one kernel: the ladder for u2*Q, then the 8-bit comb of u1*G onto the same Jacobian point
+    int rc = ensure_comb(ctx, curve, ops);
+    if (!rc && !ctx->comb_u[curve]) rc = ECCX_ERR_HIP;
+    const int fgrid = ops->var_fast_grid ? ops->var_fast_grid(ctx->cus, n) : grid_for(ctx, n);
+    if (!rc) rc = ensure_scratch(ctx, ops->info.row5_words, fgrid);
+    if (!rc) rc = ensure_rows(ctx, ops, n);
+    if (rc) { cleanup(); return rc; }
+    const uint32_t kopts = kopts_of(opts) | ((opts & ECCX_SUBTRACT) ? (1u << 5) : 0u);
+    if ((e = ops->var_fused(fgrid, ctx->stream, n, d[1], d[2], ctx->jac, d[8], ctx->scratch, kopts, d[0],
+                            ctx->comb_u[curve])) != hipSuccess)
+      return fail(e, "fused double-scalar launch");
+    if ((e = ops->to_affine_var(norm_grid(ctx, n), ctx->stream, n, ctx->jac, d[7], d[8])) != hipSuccess)
+      return fail(e, "to_affine launch");
+    if ((e = hipMemcpyAsync(out, d[7], n * pb, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) return fail(e, "hipMemcpyAsync");
+    if ((e = hipMemcpyAsync(flags, d[8], n, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) return fail(e, "hipMemcpyAsync");
+    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(e, "hipStreamSynchronize");
+    cleanup();
+    return ECCX_OK;
+  }
   int rc = eccx_scalarmul_base_dev(ctx, curve, n, d[0], d[3], d[4], nullptr, 0, ctx->stream);
   if (!rc) rc = eccx_scalarmul_var_dev(ctx, curve, n, d[1], d[2], d[5], d[6], nullptr, opts & ECCX_VALIDATE_POINTS, ctx->stream);
   if (rc) { cleanup(); return rc; }

@@ -174,11 +174,22 @@ template <class CU>
 constexpr int unsat_occupancy() { return CU::N <= 9 ? 4 : (CU::N <= 14 ? ECCX_OCC_U14 : ECCX_OCC_U18); }
 
 template <class CU>
+constexpr int utable_words() { return ((2 * CU::N + 3) / 4) * 4; }
+template <class CU>
+ECCX_DEV void ucomb_accumulate(UJac<CU>& q, const uint8_t* __restrict__ k, const uint32_t* __restrict__ table);
+
+// FUSED: the double-scalar "verify shape" u1*G + u2*Q (src/protocol/ecdsa.rs:215) in one pass:
+// after the ladder has produced u2*Q in Jacobian form, the 8-bit-window comb of u1*G is
+// accumulated onto the same point (base_scalars, utable as for k_scalarmul_base_unsat), so
+// there is one normalisation and no intermediate affine points.
+template <class CU, bool FUSED = false>
 __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_var_unsat(size_t n, const uint8_t* __restrict__ scalars,
                                                                         const uint8_t* __restrict__ points,
                                                                         uint32_t* __restrict__ rows_out,
                                                                         uint8_t* __restrict__ flags,
-                                                                        uint32_t* __restrict__ scratch, uint32_t opts) {
+                                                                        uint32_t* __restrict__ scratch, uint32_t opts,
+                                                                        const uint8_t* __restrict__ base_scalars = nullptr,
+                                                                        const uint32_t* __restrict__ utable = nullptr) {
   using CS = typename CU::Sat;
   constexpr int L = CS::L;
   constexpr int FB = CS::FB;
@@ -210,6 +221,9 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_var_uns
       }
       q.x = u_as<1, 3>(u_to_mont<CU>(rx));
       q.y = u_as<1, 3>(u_to_mont<CU>(ry));
+    }
+    if constexpr (FUSED) {
+      if (opts & OPT_NEGATE_B) q.y = u_reduce(u_neg(q.y));  // u1*G - u2*Q
     }
     U<CU, 1, 2> one;
 #pragma unroll
@@ -311,6 +325,7 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_var_uns
         }
       }
     }
+    if constexpr (FUSED) ucomb_accumulate<CU>(q, base_scalars + idx * (size_t)SB, utable);
     if (active) {
       Pt<CS> res;  // canonical plain integers
       u_to_canonical<CU>(res.x, q.x);
@@ -348,9 +363,6 @@ ECCX_DEV void ujac_madd_raw(UJac<CU>& r, bool& h_zero, bool& r_zero, const UJac<
   r.z = u_fit<UJac<CU>::ZK, UJac<CU>::ZV>(u_mul(p.z, h));
 }
 
-template <class CU>
-constexpr int utable_words() { return ((2 * CU::N + 3) / 4) * 4; }
-
 // affine points as canonical big-endian bytes (x | y, what the engine's own variable-base path
 // produces for the table scalars) -> table entries in the unsaturated field's form
 template <class CU>
@@ -369,6 +381,54 @@ __global__ void k_affine_to_utable(size_t entries, const uint8_t* __restrict__ a
   uint32_t* o = utable + i * UW;
 #pragma unroll
   for (int k = 0; k < UW; ++k) o[k] = k < CU::N ? ux.v[k] : (k < 2 * CU::N ? uy.v[k - CU::N] : 0u);
+}
+
+// q += sum over the scalar's bytes of table[(w, byte)]: the comb loop shared by the fixed-base
+// kernel and the fused double-scalar kernel.  Jacobian mixed additions with the same special
+// cases as the variable-base ladder (accumulator at infinity, digit 0, q == -entry, q == entry).
+template <class CU>
+ECCX_DEV void ucomb_accumulate(UJac<CU>& q, const uint8_t* __restrict__ k, const uint32_t* __restrict__ table) {
+  using CS = typename CU::Sat;
+  constexpr int SB = CS::SB;
+  constexpr int NW = SB;  // one window per scalar byte
+  constexpr int UW = utable_words<CU>();
+  U<CU, 1, 2> one;
+#pragma unroll
+  for (int i = 0; i < CU::N; ++i) one.v[i] = CU::ONE[i];
+  for (int w = 0; w < NW; ++w) {
+    const uint32_t d = k[SB - 1 - w];
+    const uint4* __restrict__ e = reinterpret_cast<const uint4*>(table + ((size_t)w * 256 + (d ? d : 1)) * UW);
+    uint32_t ew[UW];
+#pragma unroll
+    for (int i = 0; i < UW / 4; ++i) {
+      const uint4 v = e[i];
+      ew[4 * i] = v.x; ew[4 * i + 1] = v.y; ew[4 * i + 2] = v.z; ew[4 * i + 3] = v.w;
+    }
+    U<CU, 1, 2> x2, y2;
+#pragma unroll
+    for (int i = 0; i < CU::N; ++i) { x2.v[i] = ew[i]; y2.v[i] = ew[CU::N + i]; }
+    const bool q_inf = u_limbs_all_zero(q.z);
+    const bool e_skip = (d == 0);
+    UJac<CU> sum;
+    bool hz, rz;
+    ujac_madd_raw<CU>(sum, hz, rz, q, x2, y2);
+    const bool same_x = hz && !q_inf && !e_skip;
+    const bool need_dbl = same_x && rz;
+    if (same_x && !rz) u_set_zero(sum.z);  // q == -entry
+    u_select(sum.x, q_inf, u_as<1, 3>(x2), sum.x);
+    u_select(sum.y, q_inf, u_as<1, 3>(y2), sum.y);
+    u_select(sum.z, q_inf, u_as<UJac<CU>::ZK, UJac<CU>::ZV>(one), sum.z);
+    if (__builtin_amdgcn_ballot_w64(need_dbl) != 0) {  // q == entry: rare, wave-uniform branch
+      UJac<CU> t;
+      ujac_dbl<CU>(t, q);
+      u_select(sum.x, need_dbl, t.x, sum.x);
+      u_select(sum.y, need_dbl, t.y, sum.y);
+      u_select(sum.z, need_dbl, t.z, sum.z);
+    }
+    u_select(q.x, e_skip, q.x, sum.x);
+    u_select(q.y, e_skip, q.y, sum.y);
+    u_select(q.z, e_skip, q.z, sum.z);
+  }
 }
 
 // Fixed-base comb: the reference's mul_base (src/curve/fiat/curve_macros.rs) adds one table
@@ -399,40 +459,7 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_base_un
     q.x = u_as<1, 3>(one);
     q.y = u_as<1, 3>(one);
     u_set_zero(q.z);  // infinity
-    for (int w = 0; w < NW; ++w) {
-      const uint32_t d = k[SB - 1 - w];
-      const uint4* __restrict__ e = reinterpret_cast<const uint4*>(table + ((size_t)w * 256 + (d ? d : 1)) * UW);
-      uint32_t ew[UW];
-#pragma unroll
-      for (int i = 0; i < UW / 4; ++i) {
-        const uint4 v = e[i];
-        ew[4 * i] = v.x; ew[4 * i + 1] = v.y; ew[4 * i + 2] = v.z; ew[4 * i + 3] = v.w;
-      }
-      U<CU, 1, 2> x2, y2;
-#pragma unroll
-      for (int i = 0; i < CU::N; ++i) { x2.v[i] = ew[i]; y2.v[i] = ew[CU::N + i]; }
-      const bool q_inf = u_limbs_all_zero(q.z);
-      const bool e_skip = (d == 0);
-      UJac<CU> sum;
-      bool hz, rz;
-      ujac_madd_raw<CU>(sum, hz, rz, q, x2, y2);
-      const bool same_x = hz && !q_inf && !e_skip;
-      const bool need_dbl = same_x && rz;
-      if (same_x && !rz) u_set_zero(sum.z);  // q == -entry
-      u_select(sum.x, q_inf, u_as<1, 3>(x2), sum.x);
-      u_select(sum.y, q_inf, u_as<1, 3>(y2), sum.y);
-      u_select(sum.z, q_inf, u_as<UJac<CU>::ZK, UJac<CU>::ZV>(one), sum.z);
-      if (__builtin_amdgcn_ballot_w64(need_dbl) != 0) {  // q == entry: rare, wave-uniform branch
-        UJac<CU> t;
-        ujac_dbl<CU>(t, q);
-        u_select(sum.x, need_dbl, t.x, sum.x);
-        u_select(sum.y, need_dbl, t.y, sum.y);
-        u_select(sum.z, need_dbl, t.z, sum.z);
-      }
-      u_select(q.x, e_skip, q.x, sum.x);
-      u_select(q.y, e_skip, q.y, sum.y);
-      u_select(q.z, e_skip, q.z, sum.z);
-    }
+    ucomb_accumulate<CU>(q, k, table);
     if (active) {
       Pt<CS> res;  // canonical plain integers
       u_to_canonical<CU>(res.x, q.x);

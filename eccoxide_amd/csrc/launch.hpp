@@ -57,6 +57,10 @@ struct CurveOps {
   hipError_t (*comb_convert)(hipStream_t s, size_t entries, const uint8_t* affine, uint32_t* utable);
   hipError_t (*base_unsat)(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint32_t* utable,
                            uint32_t* rows, uint8_t* flags);
+  // fused double-scalar u1*G + u2*Q (may be null): var_fast's ladder on (u2, q) followed by the
+  // comb of u1 over utable, rows for to_affine_var; same grid and scratch as var_fast
+  hipError_t (*var_fused)(int grid, hipStream_t s, size_t n, const uint8_t* u2, const uint8_t* q, uint32_t* rows,
+                          uint8_t* flags, uint32_t* scratch, uint32_t opts, const uint8_t* u1, const uint32_t* utable);
 };
 // units normalised per lane with one inversion: 16 where the prefix products fit the register
 // file (8-limb fields), 8 above

@@ -87,3 +87,34 @@ def test_ed25519_verify_shape(engine, oracle):
     Rpt = oracle.base("ed25519", be(r))[0]
     out, flags = engine.double_scalarmul("ed25519", be(s), be(k), A, subtract=True)
     assert out == Rpt and flags == bytes(n)
+
+
+@pytest.mark.parametrize("curve", ["p256r1", "p384r1", "p521r1", "bls12_381_g1"])
+def test_fused_accumulation_special_cases(engine, oracle, curve):
+    """The fused kernel adds the comb of u1*G onto the Jacobian u2*Q with incomplete (mixed)
+    additions.  With Q = G the two halves can be made to collide:
+      u2 = d*256^w, u1 = d*256^w      -> accumulator == table entry      (doubling case)
+      u1 = n - u2                     -> accumulator == -(last entry)    (infinity)
+      u1 = 0, u2 = 0, u2 = n          -> accumulator at infinity before / after the comb
+    and the same with subtraction (Q negated)."""
+    c = R.CURVES[curve]
+    g = oracle.base(curve, (1).to_bytes(c.sb, "big"))[0]
+    rng = random.Random(99)
+    pairs = []
+    for w, d in ((0, 1), (0, 200), (1, 7), (5, 255), (c.sb - 2, 3)):
+        k = d << (8 * w)
+        pairs += [(k, k), (c.n - k, k), (k, c.n - k)]
+    pairs += [(0, 0), (0, c.n), (c.n, 0), (5, 0), (0, 5), (c.n - 1, 1), (1, c.n - 1)]
+    for _ in range(8):
+        k = rng.randrange(1, c.n)
+        pairs += [(c.n - k, k), (k, k)]
+    n = len(pairs)
+    u1 = b"".join(a.to_bytes(c.sb, "big") for a, _ in pairs)
+    u2 = b"".join(b.to_bytes(c.sb, "big") for _, b in pairs)
+    pb = 2 * c.fb
+    for subtract in (False, True):
+        out, flags = engine.double_scalarmul(curve, u1, u2, g * n, subtract=subtract)
+        tot = [((a - b) if subtract else (a + b)) % c.n for a, b in pairs]
+        want = oracle.base(curve, b"".join(t.to_bytes(c.sb, "big") for t in tot))
+        assert out == want[0] and flags == want[1], (curve, subtract)
+        assert any(f == 1 for f in flags)   # some of them are the point at infinity
