@@ -71,6 +71,57 @@ def test_engine_side_constants_match_reference():
         assert limbs("PM2")[0] == p - 2
 
 
+def test_unsaturated_field_constants_match_reference():
+    """The digit tables of the unsaturated field layer (ufe.hpp) against the curve parameters:
+    modulus, p + 1 and its Solinas / sparse terms, the 4p subtraction bias (every limb at least
+    the largest tight digit), Montgomery constants, generator."""
+    import re
+
+    txt = open(oracle_lib.ROOT + "/eccoxide_amd/csrc/curve_consts.inc").read()
+    cases = (("P256U", R.CURVES["p256r1"]), ("P384U", R.CURVES["p384r1"]), ("P521U", R.CURVES["p521r1"]),
+             ("BLS12_381U", R.CURVES["bls12_381_g1"]), ("ED25519U", R.ED25519))
+    for sname, c in cases:
+        body = txt[txt.index("struct %s {" % sname):]
+        body = body[: body.index("\n};")]
+        num = lambda f: int(re.search(r"%s = (-?\w+?)u?;" % f, body).group(1), 0)
+        N, B, kind = num("N"), num("B"), num("KIND")
+
+        def arr(field):
+            m = re.search(r"(?:uint32_t|int) %s\[\d+\] = \{([^}]*)\}" % field, body)
+            return [int(v.strip().rstrip("u"), 0) for v in m.group(1).split(",")]
+
+        val = lambda field: sum(v << (B * i) for i, v in enumerate(arr(field)))
+        p = c.p
+        mont = kind in (0, 1)
+        Rm = (1 << (B * N)) if mont else 1
+        assert B * N >= p.bit_length() and num("PBITS") == p.bit_length()
+        assert val("P") == p and val("PP1") == p + 1 and val("P2") == 2 * p
+        assert all(d < (1 << B) for f in ("P", "PP1", "ONE", "R2", "GX", "GY") for d in arr(f)[:-1])
+        assert val("ONE") == Rm % p and val("R2") == Rm * Rm % p
+        assert val("GX") == c.gx * Rm % p and val("GY") == c.gy * Rm % p
+        bias = arr("BIAS")
+        assert val("BIAS") == 4 * p and all(d >= (1 << B) - 1 for d in bias[:-1]) and all(d < (1 << (B + 1)) for d in bias)
+        assert num("TOPSHIFT") == p.bit_length() - B * (N - 1)
+        assert num("N0B") == (-pow(p, -1, 1 << B)) % (1 << B)
+        if kind == 0:
+            assert p % (1 << B) == (1 << B) - 1          # the Montgomery factor is the low limb itself
+        if kind in (2, 3):
+            assert num("FOLD") == (1 << (B * N)) % p
+        if num("SOL_N"):
+            terms = sum(sg << (B * l + sh) for l, sh, sg in zip(arr("SOL_LIMB"), arr("SOL_SHIFT"), arr("SOL_SIGN")))
+            assert (1 << p.bit_length()) + terms == p + 1
+        if num("SPARSE_N"):
+            terms = sum(sg << (B * o + sh) for o, sh, sg in zip(arr("SPARSE_OFF"), arr("SPARSE_SHIFT"), arr("SPARSE_SIGN")))
+            assert terms == p + 1
+        if num("QMUL"):
+            ptop = p >> (B * (N - 1))
+            assert num("QMUL") == (1 << 32) // (ptop + 1)
+    d2 = txt[txt.index("struct ED25519U {"):]
+    d2 = d2[: d2.index("\n};")]
+    vals = [int(v.strip().rstrip("u"), 16) for v in re.search(r"uint32_t D2\[9\] = \{([^}]*)\}", d2).group(1).split(",")]
+    assert sum(v << (29 * i) for i, v in enumerate(vals)) == 2 * R.ED25519.d % R.ED25519.p
+
+
 # ---- NIST kG (src/tests/kats.rs:3-40 over kats_data.rs) ----------------------------
 @pytest.mark.parametrize("name", ["p256r1", "p384r1", "p521r1"])
 def test_nist_kg_python_oracle(name):
