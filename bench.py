@@ -91,14 +91,14 @@ WORKLOADS = {
 # read from inside this process, so the figure is the committed measurement of this very
 # workload, not a live one; null where no profile has been taken.
 MEASURED_TRAFFIC = {
-    "p256r1_var_2^20": {"bytes": 2 * (8300380608 + 112711285) + 4666984490 + 105912394,
-                        "fetch_raw": 8300380608 + 112711285, "write": 4666984490 + 105912394,
+    "p256r1_var_2^20": {"bytes": 2 * (7523101514 + 96229988) + 3672627365 + 103818322,
+                        "fetch_raw": 7523101514 + 96229988, "write": 3672627365 + 103818322,
                         "source": "profiles/r01_p256r1_var_u29.json"},
-    "ed25519_base_2^20": {"bytes": 2 * (23534773 + 112726219) + 117074368 + 105956811,
-                          "fetch_raw": 23534773 + 112726219, "write": 117074368 + 105956811,
+    "ed25519_base_2^20": {"bytes": 2 * (24184522 + 94970282) + 101712320 + 103857045,
+                          "fetch_raw": 24184522 + 94970282, "write": 101712320 + 103857045,
                           "source": "profiles/r01_ed25519_base.json"},
-    "x25519_2^20": {"bytes": 2 * (31294638 + 111890286) + 101712549 + 72351863,
-                    "fetch_raw": 31294638 + 111890286, "write": 101712549 + 72351863,
+    "x25519_2^20": {"bytes": 2 * (31290340 + 92848283) + 101712128 + 70254601,
+                    "fetch_raw": 31290340 + 92848283, "write": 101712128 + 70254601,
                     "source": "profiles/r01_x25519.json"},
 }
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec

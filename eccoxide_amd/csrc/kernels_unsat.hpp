@@ -675,10 +675,11 @@ ECCX_DEV void ued_dbl(UEd<CU>& r, const UEd<CU>& p) {
   auto b = u_sqr(p.y);
   auto zz = u_sqr(p.z);
   auto xy = u_sqr(u_add(p.x, p.y));
-  auto e = u_reduce(u_sub(u_sub(xy, a), b));      // E = (X+Y)^2 - A - B
-  auto g = u_reduce(u_sub(b, a));                 // G = D + B = B - A      (D = -A)
+  // two carry chains (F and H) are enough: E (K = 5) and G (K = 3) only meet tight factors
+  auto e = u_sub(u_sub(xy, a), b);                // E = (X+Y)^2 - A - B
+  auto g = u_sub(b, a);                           // G = D + B = B - A      (D = -A)
   auto f = u_reduce(u_sub(u_sub(g, zz), zz));     // F = G - 2 Z^2
-  auto h = u_sub(u_neg(a), b);                    // H = D - B = -(A + B)
+  auto h = u_reduce(u_sub(u_neg(a), b));          // H = D - B = -(A + B)
   r.x = u_fit<1, 3>(u_mul(e, f));
   r.y = u_fit<1, 3>(u_mul(g, h));
   r.z = u_fit<1, 3>(u_mul(f, g));

@@ -381,7 +381,11 @@ ECCX_DEV U<C, 1, 3> u_reduce(const U<C, K1, V1>& a) {
     int64_t acc = 0;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-      acc += (int64_t)a.v[i];
+      {  // acc += a[i]: one v_mad_u64_u32 by 1 instead of an add-with-carry pair
+        uint64_t u = (uint64_t)acc;
+        umad1_k(u, a.v[i], 1u);
+        acc = (int64_t)u;
+      }
       if (C::P[i] != 0) acc += (int64_t)nq * (int64_t)(int32_t)C::P[i];
       if (i < N - 1) {
         r.v[i] = (uint32_t)acc & C::MASK;
