@@ -41,11 +41,18 @@ hipError_t base_w8_(int grid, hipStream_t s, size_t n, const uint8_t* scalars, c
 }
 hipError_t var_fast_(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint8_t* points, uint32_t* rows,
                      uint8_t* flags, uint32_t* scratch, uint32_t opts) {
-  hipLaunchKernelGGL(k_ed_scalarmul_var_unsat<ED25519U>, dim3(grid), dim3(WG), 0, s, n, scalars, points, rows, flags, scratch, opts);
+  hipLaunchKernelGGL((k_ed_scalarmul_var_unsat<ED25519U, false>), dim3(grid), dim3(WG), 0, s, n, scalars, points, rows, flags, scratch,
+                     opts, nullptr, nullptr);
+  return hipGetLastError();
+}
+hipError_t var_fused_(int grid, hipStream_t s, size_t n, const uint8_t* u2, const uint8_t* q, uint32_t* rows, uint8_t* flags,
+                      uint32_t* scratch, uint32_t opts, const uint8_t* u1, const uint32_t* utable) {
+  hipLaunchKernelGGL((k_ed_scalarmul_var_unsat<ED25519U, true>), dim3(grid), dim3(WG), 0, s, n, u2, q, rows, flags, scratch, opts,
+                     u1, utable);
   return hipGetLastError();
 }
 int var_fast_grid_(int cus, size_t n) {
-  static const int occ = occupancy_per_cu(k_ed_scalarmul_var_unsat<ED25519U>);
+  static const int occ = occupancy_per_cu(k_ed_scalarmul_var_unsat<ED25519U, false>);
   return persistent_grid(occ, cus, n);
 }
 int var_grid_(int cus, size_t n) {
@@ -69,7 +76,7 @@ hipError_t launch_x25519_to_u(int grid, hipStream_t s, size_t n, const uint32_t*
   return hipGetLastError();
 }
 const CurveOps& ops_ED25519() {
-  static const CurveOps o = {{ED25519::FB, ED25519::SB, ED25519::L, 4 * ED25519::L, 0, 1, ED_VAR_ROW_WORDS, row_words<ED25519::L>()}, var_, base_, var_fast_, nullptr, nullptr, base_lds_, to_affine_hom_, var_grid_, var_fast_grid_, to_affine_hom_, point_add_, ED_U_ENTRY_WORDS, comb_convert_, base_w8_, nullptr};
+  static const CurveOps o = {{ED25519::FB, ED25519::SB, ED25519::L, 4 * ED25519::L, 0, 1, ED_VAR_ROW_WORDS, row_words<ED25519::L>()}, var_, base_, var_fast_, nullptr, nullptr, base_lds_, to_affine_hom_, var_grid_, var_fast_grid_, to_affine_hom_, point_add_, ED_U_ENTRY_WORDS, comb_convert_, base_w8_, var_fused_};
   return o;
 }
 }  // namespace eccx

@@ -572,6 +572,46 @@ __global__ void __launch_bounds__(WG, 4) k_x25519_ladder_unsat(size_t n, const u
 // 28 words each, L2 resident): 32 seven-product additions instead of 64.  The only carry chain
 // per addition is the reduction of F = 2Z - C, which feeds two products.
 constexpr int ED_U_ENTRY_WORDS = 28;
+
+// (x, y, z, t) += the table point given as (y2 - x2, y2 + x2, 2d*x2*y2), Z2 = 1: Point::add with
+// the operand prepared in the table (curve25519.rs:695-729), 7 products
+template <class CU>
+ECCX_DEV void ued_add_niels(U<CU, 1, 3>& qx, U<CU, 1, 3>& qy, U<CU, 1, 3>& qz, U<CU, 1, 3>& qt, const U<CU, 1, 3>& ym,
+                            const U<CU, 1, 3>& yp, const U<CU, 1, 3>& t2d) {
+  auto aa = u_mul(u_sub(qy, qx), ym);
+  auto bb = u_mul(u_add(qy, qx), yp);
+  auto cc = u_mul(qt, t2d);
+  auto dd = u_add(qz, qz);
+  auto e = u_sub(bb, aa);
+  auto f = u_reduce(u_sub(dd, cc));
+  auto g = u_add(dd, cc);
+  auto h = u_add(bb, aa);
+  qx = u_fit<1, 3>(u_mul(e, f));
+  qy = u_fit<1, 3>(u_mul(g, h));
+  qz = u_fit<1, 3>(u_mul(f, g));
+  qt = u_fit<1, 3>(u_mul(e, h));
+}
+
+// q += sum over the bytes of k of table[(w, byte)] (the 8-bit-window comb; complete additions)
+template <class CU>
+ECCX_DEV void ued_comb_accumulate(U<CU, 1, 3>& qx, U<CU, 1, 3>& qy, U<CU, 1, 3>& qz, U<CU, 1, 3>& qt,
+                                  const uint8_t* __restrict__ k, const uint32_t* __restrict__ table) {
+  constexpr int N = CU::N;
+  for (int w = 0; w < 32; ++w) {
+    const uint32_t d = k[31 - w];  // big-endian scalar bytes (curve25519.rs:842-846)
+    const uint4* __restrict__ e4 = reinterpret_cast<const uint4*>(table + ((size_t)w * 256 + d) * ED_U_ENTRY_WORDS);
+    uint32_t ew[ED_U_ENTRY_WORDS];
+#pragma unroll
+    for (int i = 0; i < ED_U_ENTRY_WORDS / 4; ++i) {
+      const uint4 v = e4[i];
+      ew[4 * i] = v.x; ew[4 * i + 1] = v.y; ew[4 * i + 2] = v.z; ew[4 * i + 3] = v.w;
+    }
+    U<CU, 1, 3> ym, yp, t2d;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { ym.v[i] = ew[i]; yp.v[i] = ew[N + i]; t2d.v[i] = ew[2 * N + i]; }
+    ued_add_niels<CU>(qx, qy, qz, qt, ym, yp, t2d);
+  }
+}
 template <class CU>
 __global__ void k_ed_affine_to_niels_unsat(size_t entries, const uint8_t* __restrict__ affine, uint32_t* __restrict__ table) {
   using CS = typename CU::Sat;
@@ -613,32 +653,7 @@ __global__ void __launch_bounds__(WG, 4) k_ed_scalarmul_base_unsat(size_t n, con
     T qx, qy, qz, qt;  // the neutral element (0, 1, 1, 0)
     u_set_zero(qx); u_set_zero(qy); u_set_zero(qz); u_set_zero(qt);
     qy.v[0] = 1; qz.v[0] = 1;
-    for (int w = 0; w < 32; ++w) {
-      const uint32_t d = k[31 - w];  // big-endian scalar bytes (curve25519.rs:842-846)
-      const uint4* __restrict__ e4 = reinterpret_cast<const uint4*>(table + ((size_t)w * 256 + d) * ED_U_ENTRY_WORDS);
-      uint32_t ew[ED_U_ENTRY_WORDS];
-#pragma unroll
-      for (int i = 0; i < ED_U_ENTRY_WORDS / 4; ++i) {
-        const uint4 v = e4[i];
-        ew[4 * i] = v.x; ew[4 * i + 1] = v.y; ew[4 * i + 2] = v.z; ew[4 * i + 3] = v.w;
-      }
-      T ym, yp, t2d;
-#pragma unroll
-      for (int i = 0; i < N; ++i) { ym.v[i] = ew[i]; yp.v[i] = ew[N + i]; t2d.v[i] = ew[2 * N + i]; }
-      // Point::add with Z2 = 1 and the operand prepared in the table (curve25519.rs:695-729)
-      auto aa = u_mul(u_sub(qy, qx), ym);
-      auto bb = u_mul(u_add(qy, qx), yp);
-      auto cc = u_mul(qt, t2d);
-      auto dd = u_add(qz, qz);
-      auto e = u_sub(bb, aa);
-      auto f = u_reduce(u_sub(dd, cc));
-      auto g = u_add(dd, cc);
-      auto h = u_add(bb, aa);
-      qx = u_fit<1, 3>(u_mul(e, f));
-      qy = u_fit<1, 3>(u_mul(g, h));
-      qz = u_fit<1, 3>(u_mul(f, g));
-      qt = u_fit<1, 3>(u_mul(e, h));
-    }
+    ued_comb_accumulate<CU>(qx, qy, qz, qt, k, table);
     if (active) {
       Pt<CS> row;
       u_to_canonical<CU>(row.x, qx);
@@ -745,11 +760,16 @@ ECCX_DEV void ued_row_load(UEdCached<CU>& c, const uint32_t* __restrict__ row) {
   for (int i = 0; i < N; ++i) { c.ym.v[i] = w[i]; c.yp.v[i] = w[N + i]; c.z2.v[i] = w[2 * N + i]; c.t2d.v[i] = w[3 * N + i]; }
 }
 
-template <class CU>
+// FUSED: the verify shape [u1]B + [u2]A ([u1]B - [u2]A with OPT_NEGATE_B; src/protocol/ed25519.rs:145)
+// in one pass: the ladder keeps T through its additions and the 8-bit comb of u1*B is accumulated
+// onto its result (base_scalars, utable as for k_ed_scalarmul_base_unsat).
+template <class CU, bool FUSED = false>
 __global__ void __launch_bounds__(WG, 4) k_ed_scalarmul_var_unsat(size_t n, const uint8_t* __restrict__ scalars,
                                                                   const uint8_t* __restrict__ points,
                                                                   uint32_t* __restrict__ rows_out, uint8_t* __restrict__ flags,
-                                                                  uint32_t* __restrict__ scratch, uint32_t opts) {
+                                                                  uint32_t* __restrict__ scratch, uint32_t opts,
+                                                                  const uint8_t* __restrict__ base_scalars = nullptr,
+                                                                  const uint32_t* __restrict__ utable = nullptr) {
   using CS = typename CU::Sat;
   constexpr int L = CS::L;
   constexpr int N = CU::N;
@@ -788,6 +808,9 @@ __global__ void __launch_bounds__(WG, 4) k_ed_scalarmul_var_unsat(size_t n, cons
       }
       p.x = u_reduce(u_as<1, 3>(u_from_sat<CU>(rx)));
       p.y = u_reduce(u_as<1, 3>(u_from_sat<CU>(ry)));
+    }
+    if constexpr (FUSED) {
+      if (opts & OPT_NEGATE_B) p.x = u_reduce(u_neg(p.x));  // -(x, y) = (-x, y) (curve25519.rs:731-738)
     }
     u_set_zero(p.z);
     p.z.v[0] = 1;
@@ -847,9 +870,11 @@ __global__ void __launch_bounds__(WG, 4) k_ed_scalarmul_var_unsat(size_t n, cons
       UEdCached<CU> c;
       ued_row_load<CU>(c, row(d));
       UEd<CU> s;
-      ued_add<CU, false>(s, q, c, neg);
+      ued_add<CU, FUSED>(s, q, c, neg);  // the comb that follows needs T
       q.x = s.x; q.y = s.y; q.z = s.z;
+      if constexpr (FUSED) q.t = s.t;
     }
+    if constexpr (FUSED) ued_comb_accumulate<CU>(q.x, q.y, q.z, q.t, base_scalars + idx * 32, utable);
     if (active) {
       Pt<CS> res;
       u_to_canonical<CU>(res.x, q.x);

@@ -139,10 +139,10 @@ int eccx_point_add(eccx_ctx* ctx, int curve, size_t n, const uint8_t* a, const u
 /* Double-scalar "verify shape": out[i] = u1[i]*G + u2[i]*Q[i]  (u1*G - u2*Q with ECCX_SUBTRACT).
  * The batched form of ECDSA verification's u1*G + u2*Q (src/protocol/ecdsa.rs:215) and of
  * Ed25519's [s]B - [k]A (src/protocol/ed25519.rs:145; the reference uses the variable-time
- * double_scalar_mul_base_vartime, src/curve/curve25519.rs:1157-1183 -- same point).  Weierstrass
- * curves: ONE kernel, the variable-base ladder for u2*Q followed by the 8-bit-window comb of u1*G
- * accumulated onto the same Jacobian point, one normalisation.  edwards25519: composed on the
- * device from the fixed-base comb, the variable-base ladder and the complete addition.
+ * double_scalar_mul_base_vartime, src/curve/curve25519.rs:1157-1183 -- same point).  ONE kernel
+ * per curve: Weierstrass, the variable-base ladder for u2*Q followed by the 8-bit-window comb of u1*G
+ * accumulated onto the same Jacobian point, one normalisation; edwards25519 likewise with the
+ * complete extended-coordinate additions.
  *   u1, u2 : n x SB scalars      q : n x 2FB affine points      out, flags: as above
  * ECCX_VALIDATE_POINTS applies to q. */
 int eccx_double_scalarmul(eccx_ctx* ctx, int curve, size_t n, const uint8_t* u1, const uint8_t* u2,

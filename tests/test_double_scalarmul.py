@@ -118,3 +118,35 @@ def test_fused_accumulation_special_cases(engine, oracle, curve):
         want = oracle.base(curve, b"".join(t.to_bytes(c.sb, "big") for t in tot))
         assert out == want[0] and flags == want[1], (curve, subtract)
         assert any(f == 1 for f in flags)   # some of them are the point at infinity
+
+
+def test_ed25519_double_scalarmul_matches_oracle(engine, oracle):
+    """[u1]B +- [u2]A against the big-int oracle, on subgroup points, on points with an 8-torsion
+    part, and with zero / edge scalars on either side (the fused Edwards kernel has no special
+    cases: the unified additions are complete)."""
+    from tests.test_gpu_parity import _ed25519_points_outside_the_subgroup
+
+    c = R.ED25519
+    rng = random.Random(25519)
+    le = lambda v: v.to_bytes(32, "little")
+    sub = oracle.base("ed25519", W.random_scalars("ed25519", 24, seed=5).tobytes())[0]
+    mixed = b"".join(le(x) + le(y) for x, y in _ed25519_points_outside_the_subgroup(16))
+    special = le(0) + le(1) + le(0) + le(c.p - 1)
+    q = sub + mixed + special
+    n = len(q) // 64
+    edge = [0, 1, 2, 8, c.n - 1, c.n, c.n + 1, (1 << 256) - 1]
+    u1 = [rng.randrange(1 << 256) if i % 3 else edge[i % len(edge)] for i in range(n)]
+    u2 = [rng.randrange(1 << 256) if i % 4 else edge[(i // 4) % len(edge)] for i in range(n)]
+    be = lambda xs: b"".join(x.to_bytes(32, "big") for x in xs)
+    A = oracle.base("ed25519", be(u1))[0]
+    B = oracle.var("ed25519", be(u2), q)[0]
+    pt = lambda buf, i: (int.from_bytes(buf[64 * i:64 * i + 32], "little"), int.from_bytes(buf[64 * i + 32:64 * i + 64], "little"))
+    for subtract in (False, True):
+        out, flags = engine.double_scalarmul("ed25519", be(u1), be(u2), q, subtract=subtract)
+        for i in range(n):
+            P, Q = pt(A, i), pt(B, i)
+            if subtract:
+                Q = ((-Q[0]) % c.p, Q[1])
+            x, y = R.ed_affine_add(c, P, Q)
+            assert out[64 * i:64 * i + 64] == le(x) + le(y), (i, subtract)
+            assert flags[i] == (1 if (x, y) == (0, 1) else 0)
