@@ -81,6 +81,10 @@ WORKLOADS = {
     "ed25519_var_2^20": ("ed25519", "var", 1 << 20, 160,
                          {"mad": (51 * 20 + 4) * 54 + (51 * 16 + 52 * 7 + 4 + 14 * 8 + 16 + 1) * 90,
                           "pair": ((380 + 15) // 16 + 7) * (8 * 8 + 8)}),
+    # verify shape u1*G + u2*Q: the variable-base ladder + 32 mixed additions (8 products + 3 squares)
+    "p256r1_verify_2^20": ("p256r1", "dsm", 1 << 20, 192,
+                           {"mad": _var_unsat(9, 4, 32, 0, 383, 88, norm_u=16)["mad"] + 32 * (8 * 117 + 3 * 81),
+                            "pair": _var_unsat(9, 4, 32, 0, 383, 88, norm_u=16)["pair"]}),
     "p384r1_var_2^19": ("p384r1", "var", 1 << 19, 240, _var_unsat(14, 4, 48, 0, 575, 12 * 12 + 12 * 10)),
     "p521r1_var_2^19": ("p521r1", "var", 1 << 19, 330, _var_unsat(18, 0, 66, 0, 780, 17 * 17, mont=False)),
     "bls12_381_g1_var_2^20": ("bls12_381_g1", "var", 1 << 20, 224, _var_unsat(14, 14, 32, 1, 570, 2 * 12 * 12)),
@@ -158,10 +162,13 @@ def main():
 
     # synthetic inputs, resident in HBM before the timed region (every rank its own shard seed)
     ks = torch.from_numpy(W.random_scalars(curve, n, seed=10 + rank)).to(dev)
-    if op == "var":
+    ks2 = None
+    if op in ("var", "dsm"):
         rs = torch.from_numpy(W.random_scalars(curve, n, seed=1000 + rank)).to(dev)
         pts, _ = eng.scalarmul_base_t(curve, rs)  # r_i * G: bases in the prime-order subgroup
         del rs
+        if op == "dsm":
+            ks2 = torch.from_numpy(W.random_scalars(curve, n, seed=2000 + rank)).to(dev)
     elif op == "x25519":
         rs = torch.from_numpy(W.random_scalars(curve, n, seed=1000 + rank)).to(dev)
         pts, _ = eng.x25519_t(rs)  # peer public keys X25519(r_i, 9)
@@ -182,6 +189,8 @@ def main():
         out, flags = outs[slot], flagss[slot]
         if op == "var":
             eng.scalarmul_var_t(curve, ks, pts, out, flags, stream=stream.cuda_stream, mirror=mirror)
+        elif op == "dsm":
+            eng.double_scalarmul_t(curve, ks, ks2, pts, out, flags, stream=stream.cuda_stream)
         elif op == "x25519":
             eng.x25519_t(ks, pts, out, flags, stream=stream.cuda_stream)
         else:
@@ -238,6 +247,19 @@ def main():
         s_k = ks[idx].cpu().numpy().tobytes()
         if op == "var":
             w_out, w_inf, _ = ora.var(curve, s_k, pts[idx].cpu().numpy().tobytes(), threads=8)
+        elif op == "dsm":
+            # u1*G and u2*Q from the C oracle, their sum with textbook affine arithmetic
+            from oracle import ecc_ref as R
+
+            c = R.CURVES[curve]
+            a_out, a_inf, _ = ora.base(curve, s_k, threads=8)
+            b_out, b_inf, _ = ora.var(curve, ks2[idx].cpu().numpy().tobytes(), pts[idx].cpu().numpy().tobytes(), threads=8)
+            pb = 2 * fb
+            dec = lambda buf, fl, i: None if fl[i] else (int.from_bytes(buf[i * pb:i * pb + fb], "big"),
+                                                         int.from_bytes(buf[i * pb + fb:(i + 1) * pb], "big"))
+            sums = [R.affine_add(c, dec(a_out, a_inf, i), dec(b_out, b_inf, i)) for i in range(len(a_inf))]
+            w_out = b"".join(bytes(pb) if t is None else t[0].to_bytes(fb, "big") + t[1].to_bytes(fb, "big") for t in sums)
+            w_inf = bytes(1 if t is None else 0 for t in sums)
         elif op == "x25519":
             w_out, w_inf = ora.x25519(s_k, pts[idx].cpu().numpy().tobytes(), threads=8)
         else:
@@ -247,10 +269,13 @@ def main():
             cores = min(16, os.cpu_count() or 1)
             m = min(n, args.cpu_sample)
             c_k = ks[:m].cpu().numpy().tobytes()
-            c_p = pts[:m].cpu().numpy().tobytes() if op in ("var", "x25519") else None
+            c_p = pts[:m].cpu().numpy().tobytes() if op in ("var", "x25519", "dsm") else None
             t1 = time.perf_counter()
             if op == "var":
                 ora.var(curve, c_k, c_p, threads=cores)
+            elif op == "dsm":   # the two scalar multiplications dominate; the final addition is not timed
+                ora.base(curve, c_k, threads=cores)
+                ora.var(curve, ks2[:m].cpu().numpy().tobytes(), c_p, threads=cores)
             elif op == "x25519":
                 ora.x25519(c_k, c_p, threads=cores)
             else:
@@ -271,8 +296,8 @@ def main():
         mul_rate = (mult["mad"] + mult["pair"]) * n / (kernel_ms * 1e-3)
         line = {
             "metric": "variable-base scalarmuls/sec (batch) per GPU + achieved HBM GB/s vs roofline"
-            if op == "var" else ("X25519 scalarmuls/sec (batch) per GPU + achieved HBM GB/s vs roofline" if op == "x25519"
-                                 else "fixed-base scalarmuls/sec (batch) per GPU + achieved HBM GB/s vs roofline"),
+            if op == "var" else ("double-scalar u1*G + u2*Q /sec (batch) per GPU + achieved HBM GB/s vs roofline" if op == "dsm" else ("X25519 scalarmuls/sec (batch) per GPU + achieved HBM GB/s vs roofline" if op == "x25519"
+                                 else "fixed-base scalarmuls/sec (batch) per GPU + achieved HBM GB/s vs roofline")),
             "value": value,
             "unit": "scalarmuls/s",
             "n_gpus": world,

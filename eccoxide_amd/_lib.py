@@ -29,6 +29,7 @@ SYMBOLS = {
     "eccx_point_add": (c_int, [c_void_p, c_int, c_size_t, _u8p, _u8p, _u8p, _u8p, _u8p, _u8p, c_uint32]),
     "eccx_double_scalarmul": (c_int, [c_void_p, c_int, c_size_t, _u8p, _u8p, _u8p, _u8p, _u8p, c_uint32]),
     "eccx_x25519": (c_int, [c_void_p, c_size_t, _u8p, _u8p, _u8p, _u8p, c_uint32]),
+    "eccx_double_scalarmul_dev": (c_int, [c_void_p, c_int, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p]),
     "eccx_x25519_dev": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p]),
     "eccx_comb_table": (c_int, [c_void_p, c_int, _u8p]),
     "eccx_scalarmul_var_sharded": (c_int, [POINTER(c_void_p), c_int, c_int, c_size_t, _u8p, _u8p, _u8p, _u8p, c_uint32]),

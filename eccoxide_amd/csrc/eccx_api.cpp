@@ -486,6 +486,34 @@ int eccx_point_add(eccx_ctx* ctx, int curve, size_t n, const uint8_t* a, const u
   return ECCX_OK;
 }
 
+int eccx_double_scalarmul_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_u1, const void* d_u2, const void* d_q,
+                              void* d_out, void* d_flags, uint32_t opts, void* stream) {
+  const CurveOps* ops = ops_of(curve);
+  if (!ctx) return ECCX_ERR_ARG;
+  if (!ops) return ECCX_ERR_CURVE;
+  if (n == 0) return ECCX_OK;
+  if (!d_u1 || !d_u2 || !d_q || !d_out || !d_flags) return ECCX_ERR_ARG;
+  if (!ops->var_fused || !ops->to_affine_var) return ECCX_ERR_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // one kernel: the ladder for u2*Q, then the 8-bit comb of u1*G onto the same point
+  int rc = ensure_comb(ctx, curve, ops);
+  if (rc) return rc;
+  if (!ctx->comb_u[curve]) return ECCX_ERR_HIP;
+  hipStream_t s = static_cast<hipStream_t>(stream);  // NULL = HIP's default stream
+  const int grid = ops->var_fast_grid ? ops->var_fast_grid(ctx->cus, n) : grid_for(ctx, n);
+  rc = ensure_scratch(ctx, ops->info.row5_words, grid);
+  if (rc) return rc;
+  rc = ensure_rows(ctx, ops, n);
+  if (rc) return rc;
+  const uint32_t kopts = kopts_of(opts) | ((opts & ECCX_SUBTRACT) ? (1u << 5) : 0u);
+  HIP_TRY(ctx, ops->var_fused(grid, s, n, static_cast<const uint8_t*>(d_u2), static_cast<const uint8_t*>(d_q), ctx->jac,
+                              static_cast<uint8_t*>(d_flags), ctx->scratch, kopts, static_cast<const uint8_t*>(d_u1),
+                              ctx->comb_u[curve]));
+  HIP_TRY(ctx, ops->to_affine_var(norm_grid(ctx, n), s, n, ctx->jac, static_cast<uint8_t*>(d_out),
+                                  static_cast<uint8_t*>(d_flags)));
+  return ECCX_OK;
+}
+
 int eccx_double_scalarmul(eccx_ctx* ctx, int curve, size_t n, const uint8_t* u1, const uint8_t* u2,
                           const uint8_t* q, uint8_t* out, uint8_t* flags, uint32_t opts) {
   const CurveOps* ops = ops_of(curve);
@@ -495,61 +523,21 @@ int eccx_double_scalarmul(eccx_ctx* ctx, int curve, size_t n, const uint8_t* u1,
   if (!u1 || !u2 || !q || !out || !flags) return ECCX_ERR_ARG;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const size_t pb = 2 * (size_t)ops->info.fb, sb = (size_t)ops->info.sb;
-  // device buffers: u1, u2, q, A = u1*G, fA, B = u2*Q, fB, out, flags
-  uint8_t* d[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  const size_t sizes[9] = {n * sb, n * sb, n * pb, n * pb, n, n * pb, n, n * pb, n};
-  auto cleanup = [&]() {
-    for (auto p : d)
-      if (p) (void)hipFree(p);
-  };
-  auto fail = [&](hipError_t e, const char* what) {
-    ctx->err = std::string(what) + ": " + hipGetErrorString(e);
-    cleanup();
-    return e == hipErrorOutOfMemory ? ECCX_ERR_NOMEM : ECCX_ERR_HIP;
-  };
-  hipError_t e;
-  for (int i = 0; i < 9; ++i)
-    if ((e = hipMalloc(&d[i], sizes[i])) != hipSuccess) return fail(e, "hipMalloc");
-  const uint8_t* src[3] = {u1, u2, q};
-  for (int i = 0; i < 3; ++i)
-    if ((e = hipMemcpyAsync(d[i], src[i], sizes[i], hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
-      return fail(e, "hipMemcpyAsync");
-  if (ops->var_fused && ops->to_affine_var) {
-    // one kernel: the ladder for u2*Q, then the 8-bit comb of u1*G onto the same Jacobian point
-    int rc = ensure_comb(ctx, curve, ops);
-    if (!rc && !ctx->comb_u[curve]) rc = ECCX_ERR_HIP;
-    const int fgrid = ops->var_fast_grid ? ops->var_fast_grid(ctx->cus, n) : grid_for(ctx, n);
-    if (!rc) rc = ensure_scratch(ctx, ops->info.row5_words, fgrid);
-    if (!rc) rc = ensure_rows(ctx, ops, n);
-    if (rc) { cleanup(); return rc; }
-    const uint32_t kopts = kopts_of(opts) | ((opts & ECCX_SUBTRACT) ? (1u << 5) : 0u);
-    if ((e = ops->var_fused(fgrid, ctx->stream, n, d[1], d[2], ctx->jac, d[8], ctx->scratch, kopts, d[0],
-                            ctx->comb_u[curve])) != hipSuccess)
-      return fail(e, "fused double-scalar launch");
-    if ((e = ops->to_affine_var(norm_grid(ctx, n), ctx->stream, n, ctx->jac, d[7], d[8])) != hipSuccess)
-      return fail(e, "to_affine launch");
-    if ((e = hipMemcpyAsync(out, d[7], n * pb, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) return fail(e, "hipMemcpyAsync");
-    if ((e = hipMemcpyAsync(flags, d[8], n, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) return fail(e, "hipMemcpyAsync");
-    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(e, "hipStreamSynchronize");
-    cleanup();
-    return ECCX_OK;
-  }
-  int rc = eccx_scalarmul_base_dev(ctx, curve, n, d[0], d[3], d[4], nullptr, 0, ctx->stream);
-  if (!rc) rc = eccx_scalarmul_var_dev(ctx, curve, n, d[1], d[2], d[5], d[6], nullptr, opts & ECCX_VALIDATE_POINTS, ctx->stream);
-  if (rc) { cleanup(); return rc; }
-  rc = ensure_rows(ctx, ops, n);
-  if (rc) { cleanup(); return rc; }
-  size_t need = (n + eccx::LAUNCH_WG - 1) / eccx::LAUNCH_WG;
-  int grid = (int)std::max<size_t>(1, std::min(need, (size_t)ctx->cus * 8));
-  if ((e = ops->point_add(grid, ctx->stream, n, d[3], d[4], d[5], d[6], ctx->jac, d[8],
-                          (opts & ECCX_SUBTRACT) ? (1u << 5) : 0u)) != hipSuccess)
-    return fail(e, "point_add launch");
-  if ((e = ops->to_affine_hom(norm_grid(ctx, n), ctx->stream, n, ctx->jac, d[7], d[8])) != hipSuccess)
-    return fail(e, "to_affine launch");
-  if ((e = hipMemcpyAsync(out, d[7], n * pb, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) return fail(e, "hipMemcpyAsync");
-  if ((e = hipMemcpyAsync(flags, d[8], n, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) return fail(e, "hipMemcpyAsync");
-  if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(e, "hipStreamSynchronize");
-  cleanup();
+  DevMem mem;
+  uint8_t *d_u1 = nullptr, *d_u2 = nullptr, *d_q = nullptr, *d_o = nullptr, *d_f = nullptr;
+  HIP_TRY(ctx, mem.alloc(&d_u1, n * sb));
+  HIP_TRY(ctx, mem.alloc(&d_u2, n * sb));
+  HIP_TRY(ctx, mem.alloc(&d_q, n * pb));
+  HIP_TRY(ctx, mem.alloc(&d_o, n * pb));
+  HIP_TRY(ctx, mem.alloc(&d_f, n));
+  HIP_TRY(ctx, hipMemcpyAsync(d_u1, u1, n * sb, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_u2, u2, n * sb, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_q, q, n * pb, hipMemcpyHostToDevice, ctx->stream));
+  int rc = eccx_double_scalarmul_dev(ctx, curve, n, d_u1, d_u2, d_q, d_o, d_f, opts, ctx->stream);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(out, d_o, n * pb, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(flags, d_f, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return ECCX_OK;
 }
 

@@ -169,6 +169,31 @@ class Engine:
         self._check(rc)
         return out.raw[: n * 32], flags.raw[:n]
 
+    def double_scalarmul_t(self, curve, u1, u2, q, out=None, flags=None, *, subtract: bool = False,
+                           validate: bool = False, stream: Optional[int] = None):
+        """Device-tensor form of double_scalarmul (torch.uint8 CUDA tensors): out[i] = u1[i]*G +- u2[i]*q[i]."""
+        import torch
+
+        cid = curve_id(curve)
+        fb, sb = field_bytes(cid), scalar_bytes(cid)
+        n = u1.numel() // sb
+        if out is None:
+            out = torch.empty((n, 2 * fb), dtype=torch.uint8, device=u1.device)
+        if flags is None:
+            flags = torch.empty((n,), dtype=torch.uint8, device=u1.device)
+        for t in (u1, u2, q, out, flags):
+            if not (t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()):
+                raise ValueError("tensors must be contiguous torch.uint8 CUDA tensors")
+        if u2.numel() != n * sb or q.numel() != n * 2 * fb:
+            raise ValueError("u1, u2 and q must describe the same number of units")
+        if stream is None:
+            stream = torch.cuda.current_stream(u1.device).cuda_stream
+        rc = self._lib.eccx_double_scalarmul_dev(self._ctx, cid, n, u1.data_ptr(), u2.data_ptr(), q.data_ptr(),
+                                                 out.data_ptr(), flags.data_ptr(),
+                                                 (SUBTRACT if subtract else 0) | (VALIDATE_POINTS if validate else 0), stream)
+        self._check(rc)
+        return out, flags
+
     def x25519_t(self, scalars, u=None, out=None, flags=None, *, raw_ladder: bool = False,
                  stream: Optional[int] = None):
         """Device-tensor form of x25519 (torch.uint8 CUDA tensors, n x 32)."""

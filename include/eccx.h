@@ -147,6 +147,10 @@ int eccx_point_add(eccx_ctx* ctx, int curve, size_t n, const uint8_t* a, const u
  * ECCX_VALIDATE_POINTS applies to q. */
 int eccx_double_scalarmul(eccx_ctx* ctx, int curve, size_t n, const uint8_t* u1, const uint8_t* u2,
                           const uint8_t* q, uint8_t* out, uint8_t* flags, uint32_t opts);
+/* Device-buffer form: inputs and outputs already in this device's memory, work enqueued on
+ * `stream` (NULL = HIP's default stream), no synchronisation -- as eccx_scalarmul_var_dev. */
+int eccx_double_scalarmul_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_u1, const void* d_u2, const void* d_q,
+                              void* d_out, void* d_flags, uint32_t opts, void* stream);
 
 /* X25519: the curve25519 x-only Montgomery ladder.
  *   default            protocol::x25519::x25519 (src/protocol/x25519.rs:36-45): `scalars` are

@@ -150,3 +150,22 @@ def test_ed25519_double_scalarmul_matches_oracle(engine, oracle):
             x, y = R.ed_affine_add(c, P, Q)
             assert out[64 * i:64 * i + 64] == le(x) + le(y), (i, subtract)
             assert flags[i] == (1 if (x, y) == (0, 1) else 0)
+
+
+def test_double_scalarmul_device_tensors(engine, oracle):
+    """eccx_double_scalarmul_dev on torch tensors, on the caller's stream, against the host-buffer form."""
+    import torch
+
+    curve, n = "p256r1", 700
+    u1 = W.random_scalars(curve, n, seed=81)
+    u2 = W.random_scalars(curve, n, seed=82)
+    q = oracle.base(curve, W.random_scalars(curve, n, seed=83).tobytes())[0]
+    want = engine.double_scalarmul(curve, u1.tobytes(), u2.tobytes(), q)
+    dev = torch.device("cuda", 0)
+    t = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    stream = torch.cuda.Stream(dev)
+    with torch.cuda.stream(stream):
+        out, flags = engine.double_scalarmul_t(curve, t(u1.tobytes()).reshape(n, -1), t(u2.tobytes()).reshape(n, -1),
+                                               t(q).reshape(n, -1), stream=stream.cuda_stream)
+    stream.synchronize()
+    assert out.cpu().numpy().tobytes() == want[0] and flags.cpu().numpy().tobytes() == want[1]

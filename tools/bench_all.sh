@@ -3,7 +3,7 @@
 # usage (inside gpurun): bash tools/bench_all.sh gpurun_out/bench_all.jsonl
 OUT=${1:-gpurun_out/bench_all.jsonl}
 : > $OUT
-for w in "p256r1_var_2^20" "p256r1_base_2^20" "ed25519_base_2^20" "ed25519_var_2^20" "x25519_2^20" "p384r1_var_2^19" "p521r1_var_2^19" "bls12_381_g1_var_2^20"; do
+for w in "p256r1_var_2^20" "p256r1_base_2^20" "ed25519_base_2^20" "ed25519_var_2^20" "x25519_2^20" "p256r1_verify_2^20" "p384r1_var_2^19" "p521r1_var_2^19" "bls12_381_g1_var_2^20"; do
   timeout -k 10 400 python bench.py --steps 5 --warmup 1 --workload "$w" 2>/dev/null | tail -1 >> $OUT || exit 1
 done
 timeout -k 10 400 python bench.py --steps 5 --warmup 1 --variant mirror --no-cpu-baseline 2>/dev/null | tail -1 >> $OUT
