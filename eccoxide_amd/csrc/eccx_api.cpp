@@ -396,15 +396,6 @@ int eccx_scalarmul_base_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_sc
                                     static_cast<uint8_t*>(d_flags)));
     return ECCX_OK;
   }
-  if (!d_proj && !(opts & ECCX_MIRROR_REFERENCE) && ops->base_fast) {
-    rc = ensure_rows(ctx, ops, n);
-    if (rc) return rc;
-    HIP_TRY(ctx, ops->base_fast(grid, s, n, static_cast<const uint8_t*>(d_scalars), ctx->comb[curve], ctx->jac,
-                                static_cast<uint8_t*>(d_flags)));
-    HIP_TRY(ctx, ops->to_affine_jac(norm_grid(ctx, n), s, n, ctx->jac, static_cast<uint8_t*>(d_out),
-                                    static_cast<uint8_t*>(d_flags)));
-    return ECCX_OK;
-  }
   // LDS-staged table: forced by ECCX_TABLE_IN_LDS, excluded by ECCX_TABLE_IN_L2, otherwise used
   // for batches large enough to amortise staging 96 KiB per workgroup
   const bool lds = (opts & ECCX_TABLE_IN_LDS) || (!(opts & ECCX_TABLE_IN_L2) && n >= ((size_t)1 << 16));

@@ -1,12 +1,23 @@
-// Variable-base ladder on the unsaturated field (ufe.hpp): the default kernel for P-256.
+// Default kernels: ladders on the unsaturated field (ufe.hpp).
 //
-// Same contract and same algorithm as k_scalarmul_var_fast (kernels_fast.hpp): the reference's
-// &Point * &Scalar (src/curve/fiat/curve_macros.rs:321-327), Jacobian coordinates, signed
-// 5-bit windows, table d*P (d = 1..16) in a per-lane HBM slab, special cases patched per
-// lane, one doubling body and one addition body.  Only the field layer differs: 29-bit
-// limbs, single-instruction MACs, real squarings, carry-free additions; bounds are tracked
-// in the types (U<C, K, V>, see ufe.hpp), so an unsafe composition does not compile.
-// Results leave as canonical plain integers (rows X, Y, Z) for k_batch_to_affine<..., PLAIN>.
+//   k_scalarmul_var_unsat<CU>      the reference's &Point * &Scalar (src/curve/fiat/curve_macros.rs:
+//       321-327) on Jacobian coordinates with signed 5-bit windows (Booth recoding): table d*P,
+//       d = 1..16, in a per-lane HBM slab, then per window (MSB first) 5 doublings + 1 addition of
+//       +-d*P.  The reference's fixed 4-bit unsigned window (src/curve/projective.rs:871-896)
+//       needs 2*SB additions, this needs ceil((8*SB + 1)/5); k*P is the same point either way.
+//       <CU, true> is the fused double-scalar form u1*G + u2*Q.
+//   k_scalarmul_base_unsat<CU>     mul_base as an 8-bit-window comb over the engine's own table.
+//   k_ed_scalarmul_{var,base}_unsat, k_x25519_ladder_unsat   the edwards25519 / curve25519 forms.
+//
+// The Jacobian addition is not complete: the cases it misses are patched per lane after the
+// generic formulas ran -- accumulator at infinity -> take the table entry; digit 0 (or an entry
+// at infinity) -> keep the accumulator; equal x and opposite y -> infinity; equal points -> the
+// lane keeps its accumulator and the wavefront runs one extra doubling step.  Table build and
+// main loop are ONE loop holding a single doubling body and a single addition body chosen by
+// wave-uniform control flow.  Only the field layer carries bounds: 28/29-bit limbs,
+// single-instruction MACs, real squarings, carry-free additions, bounds tracked in the types
+// (U<C, K, V>, see ufe.hpp), so an unsafe composition does not compile.  Results leave as
+// canonical plain integers (rows X, Y, Z) for k_batch_to_affine.
 #pragma once
 #include "kernels_fast.hpp"
 #include "ufe.hpp"
@@ -236,7 +247,7 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_var_uns
     }
     const uint8_t* __restrict__ k = scalars + idx * (size_t)SB;
 
-    // Booth digit of window w: |digit| in 0..16 and its sign (see k_scalarmul_var_fast)
+    // Booth digit of window w: |digit| in 0..16 and its sign
     auto booth = [&](int w, uint32_t& d, bool& neg) {
       const int pos = 5 * w - 1 + 8;
       const int bi = pos >> 3;
@@ -435,7 +446,7 @@ ECCX_DEV void ucomb_accumulate(UJac<CU>& q, const uint8_t* __restrict__ k, const
 // entry per 4-bit window with no doublings; the result k*G does not depend on the window width,
 // so this kernel uses 8-bit windows -- entry (w, d) = d * 256^w * G, half the additions -- from
 // a table the engine builds for itself (SB x 256 entries, L2 resident).  Jacobian mixed
-// additions; same special cases as k_scalarmul_base_fast.
+// additions; same special cases as the variable-base ladder.
 template <class CU>
 __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_base_unsat(size_t n, const uint8_t* __restrict__ scalars,
                                                                                   const uint32_t* __restrict__ table,
@@ -444,9 +455,7 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_base_un
   using CS = typename CU::Sat;
   constexpr int L = CS::L;
   constexpr int SB = CS::SB;
-  constexpr int NW = SB;  // one window per scalar byte
   constexpr int W3 = row_words<L>();
-  constexpr int UW = utable_words<CU>();
   for (size_t base = (size_t)blockIdx.x * WG; base < n; base += (size_t)gridDim.x * WG) {
     const size_t gid = base + threadIdx.x;
     const bool active = gid < n;
@@ -643,7 +652,6 @@ __global__ void __launch_bounds__(WG, 4) k_ed_scalarmul_base_unsat(size_t n, con
                                                                    uint32_t* __restrict__ rows_out, uint8_t* __restrict__ flags) {
   using CS = typename CU::Sat;
   constexpr int L = CS::L;
-  constexpr int N = CU::N;
   using T = U<CU, 1, 3>;
   for (size_t base = (size_t)blockIdx.x * WG; base < n; base += (size_t)gridDim.x * WG) {
     const size_t gid = base + threadIdx.x;

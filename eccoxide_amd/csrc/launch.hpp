@@ -28,13 +28,10 @@ struct CurveOps {
                     uint8_t* flags, uint8_t* proj, uint32_t* scratch, uint32_t opts);
   hipError_t (*base)(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint32_t* table, uint8_t* out,
                      uint8_t* flags, uint8_t* proj, uint32_t opts);
-  // fast path (may be null): Jacobian ladder into `jac`, then batched normalisation
+  // default path (may be null): windowed ladder on the unsaturated field into `jac` rows, then
+  // the batched normalisation to_affine_var
   hipError_t (*var_fast)(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint8_t* points,
                          uint32_t* jac, uint8_t* flags, uint32_t* scratch, uint32_t opts);
-  hipError_t (*to_affine_jac)(int grid, hipStream_t s, size_t n, const uint32_t* jac, uint8_t* out, uint8_t* flags);
-  // fast fixed-base comb (may be null): Jacobian mixed additions into `jac`
-  hipError_t (*base_fast)(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint32_t* table,
-                          uint32_t* jac, uint8_t* flags);
   // fixed-base variant with the comb table staged in LDS (may be null); picks its own grid
   hipError_t (*base_lds)(int cus, hipStream_t s, size_t n, const uint8_t* scalars, const uint32_t* table,
                          uint32_t* rows, uint8_t* flags);
@@ -44,8 +41,8 @@ struct CurveOps {
   // workgroups per CU from the occupancy query), so no workgroup waits for a slot
   int (*var_grid)(int cus, size_t n);
   int (*var_fast_grid)(int cus, size_t n);
-  // normalisation of the rows var_fast writes (Jacobian; plain integers for the unsaturated
-  // P-256 kernel, Montgomery limbs otherwise); may be null
+  // normalisation of the rows var_fast / base_unsat / var_fused write (canonical plain integers:
+  // Jacobian X, Y, Z for the Weierstrass curves, X, Y, Z for edwards25519); may be null
   hipError_t (*to_affine_var)(int grid, hipStream_t s, size_t n, const uint32_t* rows, uint8_t* out, uint8_t* flags);
   // batched group law a + b (or a - b) on affine inputs into un-normalised rows
   hipError_t (*point_add)(int grid, hipStream_t s, size_t n, const uint8_t* a, const uint8_t* a_inf, const uint8_t* b,
