@@ -66,14 +66,20 @@ def _var_unsat(n, nz, sb, a0, inv, sat_pairs, mont=True, norm_u=8):
 WORKLOADS = {
     # name: (curve, op, per-GPU batch, algorithmic bytes per unit, multiplier instructions per unit)
     "p256r1_var_2^20": ("p256r1", "var", 1 << 20, 160, _var_unsat(9, 4, 32, 0, 383, 8 * 8 + 8 * 3, norm_u=16)),
-    # fixed base, default path: 8-bit windows, 32 additions of 7 products (Edwards, 81 + 9 mads each) or
-    # of 8 products + 3 squares (P-256) on unsaturated limbs, then the saturated normalisation
+    # fixed base, default path: 16-bit windows, 16 additions of 7 products (Edwards, 81 + 9 mads each)
+    # or of 8 products + 3 squares (P-256) on unsaturated limbs, then the saturated normalisation
     "ed25519_base_2^20": ("ed25519", "base", 1 << 20, 96,
-                          {"mad": 32 * 7 * (81 + 9), "pair": ((380 + 15) // 16 + 7) * (8 * 8 + 8)}),
+                          {"mad": 16 * 7 * (81 + 9), "pair": ((380 + 15) // 16 + 7) * (8 * 8 + 8)}),
     "p256r1_base_2^20": ("p256r1", "base", 1 << 20, 96,
-                         {"mad": 32 * (8 * (81 + 36) + 3 * (45 + 36)) + 3 * (81 + 36),
+                         {"mad": 16 * (8 * (81 + 36) + 3 * (45 + 36)) + 3 * (81 + 36),
                           "pair": ((383 + 15) // 16 + 9 + 3) * (8 * 8 + 8 * 3)}),
     # unsaturated 9 x 29 ladder: per bit 5 products (81 + 9 mads), 4 squares (45 + 9), one small multiple (9 + 1)
+    "p384r1_base_2^19": ("p384r1", "base", 1 << 19, 144,
+                         {"mad": 24 * (8 * 252 + 3 * 161) + 3 * 252, "pair": ((575 + 7) // 8 + 12) * 264}),
+    "p521r1_base_2^19": ("p521r1", "base", 1 << 19, 198,
+                         {"mad": 33 * (8 * 324 + 3 * 171), "pair": ((780 + 7) // 8 + 9) * 289}),
+    "bls12_381_g1_base_2^20": ("bls12_381_g1", "base", 1 << 20, 128,
+                               {"mad": 16 * (8 * 392 + 3 * 301) + 3 * 392, "pair": ((570 + 7) // 8 + 12) * 288}),
     "x25519_2^20": ("ed25519", "x25519", 1 << 20, 96,
                     {"mad": 256 * (5 * 90 + 4 * 54 + 10), "pair": ((380 + 15) // 16 + 6) * (8 * 8 + 8)}),
     # edwards25519 variable base: 52 signed windows of 4 x (4 squares + 3 products) + (4 + 4) + a
@@ -81,9 +87,9 @@ WORKLOADS = {
     "ed25519_var_2^20": ("ed25519", "var", 1 << 20, 160,
                          {"mad": (51 * 20 + 4) * 54 + (51 * 16 + 52 * 7 + 4 + 14 * 8 + 16 + 1) * 90,
                           "pair": ((380 + 15) // 16 + 7) * (8 * 8 + 8)}),
-    # verify shape u1*G + u2*Q: the variable-base ladder + 32 mixed additions (8 products + 3 squares)
+    # verify shape u1*G + u2*Q: the variable-base ladder + 16 mixed additions (8 products + 3 squares)
     "p256r1_verify_2^20": ("p256r1", "dsm", 1 << 20, 192,
-                           {"mad": _var_unsat(9, 4, 32, 0, 383, 88, norm_u=16)["mad"] + 32 * (8 * 117 + 3 * 81),
+                           {"mad": _var_unsat(9, 4, 32, 0, 383, 88, norm_u=16)["mad"] + 16 * (8 * 117 + 3 * 81),
                             "pair": _var_unsat(9, 4, 32, 0, 383, 88, norm_u=16)["pair"]}),
     "p384r1_var_2^19": ("p384r1", "var", 1 << 19, 240, _var_unsat(14, 4, 48, 0, 575, 12 * 12 + 12 * 10)),
     "p521r1_var_2^19": ("p521r1", "var", 1 << 19, 330, _var_unsat(18, 0, 66, 0, 780, 17 * 17, mont=False)),

@@ -194,14 +194,27 @@ int ensure_comb(eccx_ctx* ctx, int curve, const CurveOps* ops) {
   int rc = launch_var(ctx, ops, rows, d_k, nullptr, reinterpret_cast<uint8_t*>(d_tab), nullptr, nullptr,
                       K_BASE_IS_GENERATOR | K_OUT_TABLE, true, ctx->stream);
   if (rc) return rc;
-  // 8-bit-window table of the unsaturated fixed-base kernel: entry (w, d) = d * 256^w * G,
-  // computed by the engine's own variable-base path
+  // wide-window table of the unsaturated fixed-base kernel: entry (w, d) = d * 2^(W*w) * G,
+  // computed by the engine's own variable-base path (entries whose scalar would not fit the
+  // scalar width belong to digits the top window cannot produce and stay zero)
   uint32_t* d_utab = nullptr;
   if (ops->base_unsat) {
-    const size_t urows = (size_t)ops->info.sb * 256, pb = 2 * (size_t)ops->info.fb;
-    std::vector<uint8_t> uk(urows * ops->info.sb, 0);
-    for (int w = 0; w < ops->info.sb; ++w)
-      for (int d = 0; d < 256; ++d) uk[((size_t)w * 256 + d) * ops->info.sb + (ops->info.sb - 1 - w)] = (uint8_t)d;
+    const int W = ops->comb_bits, sbytes = ops->info.sb;
+    const int nwin = (8 * sbytes + W - 1) / W;
+    const size_t urows = (size_t)nwin << W, pb = 2 * (size_t)ops->info.fb;
+    std::vector<uint8_t> uk(urows * sbytes, 0);
+    for (int w = 0; w < nwin; ++w)
+      for (uint32_t d = 0; d < (1u << W); ++d) {
+        uint8_t* row = uk.data() + (((size_t)w << W) + d) * sbytes;
+        bool fits = true;
+        for (int bit = 0; bit < W; ++bit)
+          if ((d >> bit) & 1u) {
+            const int pos = w * W + bit;
+            if (pos >= 8 * sbytes) { fits = false; break; }
+            row[sbytes - 1 - (pos >> 3)] |= (uint8_t)(1u << (pos & 7));
+          }
+        if (!fits) std::fill(row, row + sbytes, (uint8_t)0);
+      }
     uint8_t *d_uk = nullptr, *d_aff = nullptr, *d_fl = nullptr;
     HIP_TRY(ctx, mem.alloc(&d_uk, uk.size()));
     HIP_TRY(ctx, mem.alloc(&d_aff, urows * pb));

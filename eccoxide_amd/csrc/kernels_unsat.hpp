@@ -186,6 +186,29 @@ constexpr int unsat_occupancy() { return CU::N <= 9 ? 4 : (CU::N <= 14 ? ECCX_OC
 
 template <class CU>
 constexpr int utable_words() { return ((2 * CU::N + 3) / 4) * 4; }
+
+// Window width of the fixed-base combs: entry (w, d) = d * 2^(W*w) * G, ceil(8*SB / W) additions.
+// Measured on MI355X, ms per 2^20 units (P-256 / Ed25519): W = 8: 2.33 / 1.51, 10: 2.01 / 1.33,
+// 12: 1.78 / 1.18, 14: 1.56 / 1.05, 16: 1.37 / 0.97.  Two scalar bytes per window: tables of
+// 84-310 MB per curve (HBM has 288 GB), built once per context in 10-160 ms.
+#ifndef ECCX_COMB_BITS
+#define ECCX_COMB_BITS 16
+#endif
+template <class CU>
+constexpr int comb_bits() { return ECCX_COMB_BITS; }
+template <class CU>
+constexpr int comb_windows() { return (8 * CU::Sat::SB + comb_bits<CU>() - 1) / comb_bits<CU>(); }
+// digit w of the big-endian SB-byte scalar k in radix 2^W
+template <int W, int SB>
+ECCX_DEV uint32_t comb_digit(const uint8_t* __restrict__ k, int w) {
+  static_assert(W >= 1 && W <= 16, "window of at most three bytes");
+  const int pos = w * W;
+  const int b = pos >> 3;  // byte that holds the lowest bit, counted from the end
+  uint32_t v = k[SB - 1 - b];
+  if (b + 1 < SB) v |= (uint32_t)k[SB - 2 - b] << 8;
+  if (b + 2 < SB) v |= (uint32_t)k[SB - 3 - b] << 16;
+  return (v >> (pos & 7)) & ((1u << W) - 1u);
+}
 template <class CU>
 ECCX_DEV void ucomb_accumulate(UJac<CU>& q, const uint8_t* __restrict__ k, const uint32_t* __restrict__ table);
 
@@ -401,14 +424,15 @@ template <class CU>
 ECCX_DEV void ucomb_accumulate(UJac<CU>& q, const uint8_t* __restrict__ k, const uint32_t* __restrict__ table) {
   using CS = typename CU::Sat;
   constexpr int SB = CS::SB;
-  constexpr int NW = SB;  // one window per scalar byte
+  constexpr int W = comb_bits<CU>();
+  constexpr int NW = comb_windows<CU>();
   constexpr int UW = utable_words<CU>();
   U<CU, 1, 2> one;
 #pragma unroll
   for (int i = 0; i < CU::N; ++i) one.v[i] = CU::ONE[i];
   for (int w = 0; w < NW; ++w) {
-    const uint32_t d = k[SB - 1 - w];
-    const uint4* __restrict__ e = reinterpret_cast<const uint4*>(table + ((size_t)w * 256 + (d ? d : 1)) * UW);
+    const uint32_t d = comb_digit<W, SB>(k, w);
+    const uint4* __restrict__ e = reinterpret_cast<const uint4*>(table + (((size_t)w << W) + (d ? d : 1)) * UW);
     uint32_t ew[UW];
 #pragma unroll
     for (int i = 0; i < UW / 4; ++i) {
@@ -444,8 +468,8 @@ ECCX_DEV void ucomb_accumulate(UJac<CU>& q, const uint8_t* __restrict__ k, const
 
 // Fixed-base comb: the reference's mul_base (src/curve/fiat/curve_macros.rs) adds one table
 // entry per 4-bit window with no doublings; the result k*G does not depend on the window width,
-// so this kernel uses 8-bit windows -- entry (w, d) = d * 256^w * G, half the additions -- from
-// a table the engine builds for itself (SB x 256 entries, L2 resident).  Jacobian mixed
+// so this kernel uses W = comb_bits() = 16 bit windows -- entry (w, d) = d * 2^(W*w) * G --
+// from a table the engine builds for itself (SB/2 x 65536 entries).  Jacobian mixed
 // additions; same special cases as the variable-base ladder.
 template <class CU>
 __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_base_unsat(size_t n, const uint8_t* __restrict__ scalars,
@@ -575,10 +599,10 @@ __global__ void __launch_bounds__(WG, 4) k_x25519_ladder_unsat(size_t n, const u
 
 // ---- edwards25519 fixed base, 8-bit windows, unsaturated field ------------------------------
 // The reference's mul_base (curve25519.rs:840-851) adds one table entry per 4-bit window; k*B
-// does not depend on the window width, so the default path uses one entry per scalar BYTE --
-// entry (w, d) = d * 256^w * B as the triple (y - x, y + x, 2d*x*y), d = 0 being the neutral
-// (1, 1, 0) -- from a table the engine builds for itself (32 x 256 entries of 9 x 29-bit digits,
-// 28 words each, L2 resident): 32 seven-product additions instead of 64.  The only carry chain
+// does not depend on the window width, so the default path uses 16-bit windows -- entry (w, d) =
+// d * 2^(16 w) * B as the triple (y - x, y + x, 2d*x*y), d = 0 being the neutral (1, 1, 0) -- from a
+// table the engine builds for itself (16 x 65536 entries of 9 x 29-bit digits, 28 words each,
+// 117 MB): 16 seven-product additions instead of 64.  The only carry chain
 // per addition is the reduction of F = 2Z - C, which feeds two products.
 constexpr int ED_U_ENTRY_WORDS = 28;
 
@@ -606,9 +630,10 @@ template <class CU>
 ECCX_DEV void ued_comb_accumulate(U<CU, 1, 3>& qx, U<CU, 1, 3>& qy, U<CU, 1, 3>& qz, U<CU, 1, 3>& qt,
                                   const uint8_t* __restrict__ k, const uint32_t* __restrict__ table) {
   constexpr int N = CU::N;
-  for (int w = 0; w < 32; ++w) {
-    const uint32_t d = k[31 - w];  // big-endian scalar bytes (curve25519.rs:842-846)
-    const uint4* __restrict__ e4 = reinterpret_cast<const uint4*>(table + ((size_t)w * 256 + d) * ED_U_ENTRY_WORDS);
+  constexpr int W = comb_bits<CU>();
+  for (int w = 0; w < comb_windows<CU>(); ++w) {
+    const uint32_t d = comb_digit<W, 32>(k, w);  // the big-endian scalar string (curve25519.rs:842-846)
+    const uint4* __restrict__ e4 = reinterpret_cast<const uint4*>(table + (((size_t)w << W) + d) * ED_U_ENTRY_WORDS);
     uint32_t ew[ED_U_ENTRY_WORDS];
 #pragma unroll
     for (int i = 0; i < ED_U_ENTRY_WORDS / 4; ++i) {

@@ -47,10 +47,11 @@ struct CurveOps {
   // batched group law a + b (or a - b) on affine inputs into un-normalised rows
   hipError_t (*point_add)(int grid, hipStream_t s, size_t n, const uint8_t* a, const uint8_t* a_inf, const uint8_t* b,
                           const uint8_t* b_inf, uint32_t* rows, uint8_t* flags, uint32_t opts);
-  // fixed-base comb on the unsaturated field with 8-bit windows (may be null): its table
-  // (scalar bytes x 256 entries of utable_words) is made by comb_convert from the affine
-  // bytes of d * 256^w * G; rows go to to_affine_var
+  // fixed-base comb on the unsaturated field with wide windows (may be null): its table
+  // (windows x 2^W entries of utable_words) is made by comb_convert from the affine bytes of
+  // d * 2^(W*w) * G; rows go to to_affine_var
   int utable_words;
+  int comb_bits;  // window width W of that table: ceil(8*SB / W) windows x 2^W entries
   hipError_t (*comb_convert)(hipStream_t s, size_t entries, const uint8_t* affine, uint32_t* utable);
   hipError_t (*base_unsat)(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint32_t* utable,
                            uint32_t* rows, uint8_t* flags);
