@@ -5,6 +5,7 @@
 //   k_ed_scalarmul_base_lds  the reference-layout Ed25519 comb with the table staged in LDS.
 // The ladders themselves are in kernels_unsat.hpp (default) and kernels.hpp (reference-mirroring).
 #pragma once
+#include "inv_gcd.hpp"
 #include "kernels.hpp"
 
 namespace eccx {
@@ -104,7 +105,7 @@ __global__ void __launch_bounds__(WG) k_batch_to_affine(size_t n, const uint32_t
       else fe_mul<C>(pre[u], pre[u - 1], z);
     }
     Fe<L> inv;
-    fe_inv<C>(inv, pre[U - 1]);
+    fe_inv_fast<C>(inv, pre[U - 1]);  // division steps: a sixth of the Fermat chain (inv_gcd.hpp)
 #pragma unroll
     for (int u = U - 1; u >= 0; --u) {
       const size_t i = tile + (size_t)u * WG + threadIdx.x;
