@@ -4,6 +4,9 @@
 #ifndef ECCX_NORM_U8
 #define ECCX_NORM_U8 16
 #endif
+#ifndef ECCX_NORM_UBIG
+#define ECCX_NORM_UBIG 8
+#endif
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -62,7 +65,7 @@ struct CurveOps {
 };
 // units normalised per lane with one inversion: 16 where the prefix products fit the register
 // file (8-limb fields), 8 above
-constexpr int to_affine_u(int limbs) { return limbs <= 8 ? ECCX_NORM_U8 : 8; }
+constexpr int to_affine_u(int limbs) { return limbs <= 8 ? ECCX_NORM_U8 : ECCX_NORM_UBIG; }
 
 const CurveOps& ops_P256();
 const CurveOps& ops_P384();
