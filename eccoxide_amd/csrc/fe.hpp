@@ -344,24 +344,6 @@ ECCX_DEV void fe_from_mont(Fe<C::L>& r, const Fe<C::L>& a) {
   fe_mul_impl<C, true>(r, a, one);
 }
 
-// a^(P-2) by square-and-multiply over the compile-time exponent bits.
-// (The reference uses per-field addition chains, e.g. sec2/p256r1.rs:49-66, or
-// safegcd, field_macros.rs:692-770; any correct inverse gives the same value.)
-template <class C>
-__device__ __noinline__ void fe_inv(Fe<C::L>& r, const Fe<C::L>& a) {
-  Fe<C::L> acc = a;
-  // skip the leading one bit of the exponent
-  for (int i = C::PBITS - 2; i >= 0; --i) {
-    fe_sqr<C>(acc, acc);
-    uint32_t w = 0;
-#pragma unroll
-    for (int j = 0; j < C::L; ++j)
-      if (j == (i >> 5)) w = C::PM2[j];
-    if ((w >> (i & 31)) & 1u) fe_mul<C>(acc, acc, a);
-  }
-  r = acc;
-}
-
 // ---- byte I/O -----------------------------------------------------------------
 // big-endian FB bytes -> integer limbs (no range check, like from_bytes_unchecked_be,
 // field_macros.rs:581-596)

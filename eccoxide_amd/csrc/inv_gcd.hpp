@@ -1,11 +1,12 @@
 // Modular inversion by division steps (Bernstein-Yang "safegcd") for the batched normalisation.
 //
-// The reference inverts with Fermat's little theorem (fiat fields: z^(p-2), ~260 field
-// multiplications -- src/curve/field_macros.rs, curve25519.rs invert); the value z^-1 mod p is
-// the same whichever way it is computed.  In k_batch_to_affine the inversion is one sequential
-// chain per lane with at most one wavefront per SIMD to hide it behind, so its length IS the
-// kernel time.  Division steps need ~25 batches of (30 steps on one word + two 2x2-matrix
-// updates of 9-limb numbers) for a 256-bit field: about a sixth of the Fermat chain.
+// The reference has both: Fermat chains z^(p-2) (e.g. src/curve/sec2/p256r1.rs:49-66) and a
+// generic Bernstein-Yang inverse_safegcd over fiat's divstep (src/curve/fiat/field_macros.rs:
+// 677-770), with a unit test that the two agree (:1203-1215); z^-1 mod p is one number.  In
+// k_batch_to_affine the inversion is one sequential chain per lane with at most one wavefront
+// per SIMD to hide it behind, so its length IS the kernel time.  Division steps need ~25 batches
+// of (30 steps on one word + two 2x2-matrix updates of 9-limb numbers) for a 256-bit field:
+// about a sixth of a Fermat chain of ~260 field multiplications.
 //
 // Fixed iteration count (the delta = 1 division step, floor((49 bits + 57) / 17) steps rounded up
 // to batches of 30: valid for every odd modulus), no data-dependent control flow.

@@ -22,6 +22,7 @@
 // wave-uniform control flow, so the whole kernel stays inside the instruction cache.
 #pragma once
 #include "curve.hpp"
+#include "inv_gcd.hpp"
 
 namespace eccx {
 
@@ -89,7 +90,7 @@ ECCX_DEV bool to_affine(Fe<C::L>& ax, Fe<C::L>& ay, const Pt<C>& q) {
   Fe<C::L> z, zi, one;
   fe_set<C>(one, C::ONE);
   fe_select<C>(z, present, q.z, one);  // z_inverse_ct: substitute 1 (projective.rs:655-659)
-  fe_inv<C>(zi, z);
+  fe_inv_fast<C>(zi, z);
   fe_mul<C>(ax, q.x, zi);
   fe_mul<C>(ay, q.y, zi);
   return present;
@@ -258,7 +259,7 @@ ECCX_DEV void ed_store_result(size_t idx, const EdPt<C>& q, bool rejected, uint8
     return;
   }
   Fe<L> zi, ax, ay, t, one;
-  fe_inv<C>(zi, q.z);  // Z != 0 on a complete Edwards curve (curve25519.rs:663-666)
+  fe_inv_fast<C>(zi, q.z);  // Z != 0 on a complete Edwards curve (curve25519.rs:663-666)
   fe_mul<C>(ax, q.x, zi);
   fe_mul<C>(ay, q.y, zi);
   if (opts & OPT_OUT_TABLE) {

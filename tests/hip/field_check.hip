@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include "curve.hpp"
+#include "inv_gcd.hpp"
 #include "ufe.hpp"
 
 namespace eccx {
@@ -22,7 +23,7 @@ struct Chk {
 };
 
 enum : int { OP_MUL_TIGHT = 0, OP_MUL_LAZY = 1, OP_SQR_LAZY = 2, OP_SUB_CHAIN = 3, OP_REDUCE_MAX = 4,
-             OP_CANONICAL = 5, OP_MUL_AUTO = 6, OP_ADD_AUTO = 7, OP_REDUCE_LAZY = 8 };
+             OP_CANONICAL = 5, OP_MUL_AUTO = 6, OP_ADD_AUTO = 7, OP_REDUCE_LAZY = 8, OP_INVERT = 9 };
 
 template <class C, int K, int V>
 __device__ U<C, K, V> load_u(const uint32_t* p) {
@@ -74,6 +75,15 @@ __global__ void k_field_check(int op, const uint32_t* __restrict__ a, const uint
       auto x = load_u<C, KM, 64>(pa);
       auto y = load_u<C, KM, 64>(pb);
       store_u(po, u_reduce(u_add(u_add(x, y), u_add(x, y))));
+      break;
+    }
+    case OP_INVERT: {  // a: saturated limbs of a canonical plain integer (zero padded to N words); out likewise
+      Fe<C::Sat::L> x, y;
+#pragma unroll
+      for (int k = 0; k < C::Sat::L; ++k) x.v[k] = pa[k];
+      fe_inv_gcd<typename C::Sat>(y, x);
+#pragma unroll
+      for (int k = 0; k < N; ++k) po[k] = k < C::Sat::L ? y.v[k] : 0u;
       break;
     }
     case OP_REDUCE_LAZY:  // the bounds under which the Solinas primes reduce with shifts of q

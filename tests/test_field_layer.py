@@ -27,7 +27,7 @@ P = {
     4: 2**255 - 19,
 }
 NAMES = {0: "p256r1", 1: "p384r1", 2: "p521r1", 3: "bls12_381_g1", 4: "curve25519"}
-OP_MUL_TIGHT, OP_MUL_LAZY, OP_SQR_LAZY, OP_SUB_CHAIN, OP_REDUCE_MAX, OP_CANONICAL, OP_MUL_AUTO, OP_ADD_AUTO, OP_REDUCE_LAZY = range(9)
+OP_MUL_TIGHT, OP_MUL_LAZY, OP_SQR_LAZY, OP_SUB_CHAIN, OP_REDUCE_MAX, OP_CANONICAL, OP_MUL_AUTO, OP_ADD_AUTO, OP_REDUCE_LAZY, OP_INVERT = range(10)
 
 
 class FieldCheck:
@@ -176,3 +176,26 @@ def test_canonical_output_is_the_unique_residue(fc, curve):
     for ra, ro in zip(a, out):
         got = sum(int(x) << (32 * i) for i, x in enumerate(ro[: inf["L"]]))
         assert got == value(ra, inf["B"]) * rinv % p
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve", [0, 1, 2, 3, 4], ids=lambda c: NAMES[c])
+def test_division_step_inversion(fc, curve):
+    """inv_gcd.hpp against Python: a * a^-1 = 1 (mod p) for edge values (1, 2, p-1, p-2, powers of
+    two, all-ones patterns below p), random values, and 0 -> 0 (the reference checks its own
+    safegcd against Fermat the same way, src/curve/fiat/field_macros.rs:1203-1215)."""
+    rng = random.Random(400 + curve)
+    inf, p = fc.info(curve), P[curve]
+    N, L = inf["N"], inf["L"]
+    vals = [0, 1, 2, 3, p - 1, p - 2, (p - 1) // 2, (p + 1) // 2, 1 << (p.bit_length() - 1), (1 << (p.bit_length() - 1)) - 1]
+    vals += [1 << k for k in range(1, p.bit_length() - 1, 29)]
+    vals += [(1 << k) - 1 for k in range(2, p.bit_length() - 1, 31)]
+    vals += [p - (1 << k) for k in range(0, p.bit_length() - 2, 37)]
+    vals += [rng.randrange(1, p) for _ in range(300)]
+    vals = [v % p for v in vals]
+    rows = [[(v >> (32 * i)) & 0xFFFFFFFF if i < L else 0 for i in range(N)] for v in vals]
+    out = fc.run(curve, OP_INVERT, rows, rows)
+    for v, ro in zip(vals, out):
+        got = sum(int(x) << (32 * i) for i, x in enumerate(ro[:L]))
+        assert got < p
+        assert got == (pow(v, -1, p) if v else 0), hex(v)
