@@ -23,6 +23,12 @@
 #include "ufe.hpp"
 
 namespace eccx {
+// comb-table entries start on 128-byte boundaries (32 words): the 16-bit-window tables live in
+// HBM / Infinity Cache and every entry is a random access, so an entry that straddles a
+// sector boundary costs an extra fetch (Ed25519 mul_base: 0.84 -> 0.81 ms per 2^20)
+#ifndef ECCX_ENTRY_ALIGN
+#define ECCX_ENTRY_ALIGN 32
+#endif
 #ifndef ECCX_EXP_ROW
 #define ECCX_EXP_ROW(d) (d)
 #endif
@@ -185,7 +191,7 @@ template <class CU>
 constexpr int unsat_occupancy() { return CU::N <= 9 ? 4 : (CU::N <= 14 ? ECCX_OCC_U14 : ECCX_OCC_U18); }
 
 template <class CU>
-constexpr int utable_words() { return ((2 * CU::N + 3) / 4) * 4; }
+constexpr int utable_words() { return ((2 * CU::N + ECCX_ENTRY_ALIGN - 1) / ECCX_ENTRY_ALIGN) * ECCX_ENTRY_ALIGN; }
 
 // Window width of the fixed-base combs: entry (w, d) = d * 2^(W*w) * G, ceil(8*SB / W) additions.
 // Measured on MI355X, ms per 2^20 units (P-256 / Ed25519): W = 8: 2.33 / 1.51, 10: 2.01 / 1.33,
@@ -433,9 +439,10 @@ ECCX_DEV void ucomb_accumulate(UJac<CU>& q, const uint8_t* __restrict__ k, const
   for (int w = 0; w < NW; ++w) {
     const uint32_t d = comb_digit<W, SB>(k, w);
     const uint4* __restrict__ e = reinterpret_cast<const uint4*>(table + (((size_t)w << W) + (d ? d : 1)) * UW);
-    uint32_t ew[UW];
+    constexpr int LW = ((2 * CU::N + 3) / 4) * 4;  // words actually read (the rest of the entry is padding)
+    uint32_t ew[LW];
 #pragma unroll
-    for (int i = 0; i < UW / 4; ++i) {
+    for (int i = 0; i < LW / 4; ++i) {
       const uint4 v = e[i];
       ew[4 * i] = v.x; ew[4 * i + 1] = v.y; ew[4 * i + 2] = v.z; ew[4 * i + 3] = v.w;
     }
@@ -604,7 +611,7 @@ __global__ void __launch_bounds__(WG, 4) k_x25519_ladder_unsat(size_t n, const u
 // table the engine builds for itself (16 x 65536 entries of 9 x 29-bit digits, 28 words each,
 // 117 MB): 16 seven-product additions instead of 64.  The only carry chain
 // per addition is the reduction of F = 2Z - C, which feeds two products.
-constexpr int ED_U_ENTRY_WORDS = 28;
+constexpr int ED_U_ENTRY_WORDS = ((27 + ECCX_ENTRY_ALIGN - 1) / ECCX_ENTRY_ALIGN) * ECCX_ENTRY_ALIGN;
 
 // (x, y, z, t) += the table point given as (y2 - x2, y2 + x2, 2d*x2*y2), Z2 = 1: Point::add with
 // the operand prepared in the table (curve25519.rs:695-729), 7 products
@@ -634,9 +641,10 @@ ECCX_DEV void ued_comb_accumulate(U<CU, 1, 3>& qx, U<CU, 1, 3>& qy, U<CU, 1, 3>&
   for (int w = 0; w < comb_windows<CU>(); ++w) {
     const uint32_t d = comb_digit<W, 32>(k, w);  // the big-endian scalar string (curve25519.rs:842-846)
     const uint4* __restrict__ e4 = reinterpret_cast<const uint4*>(table + (((size_t)w << W) + d) * ED_U_ENTRY_WORDS);
-    uint32_t ew[ED_U_ENTRY_WORDS];
+    constexpr int LW = ((3 * N + 3) / 4) * 4;  // words actually read (the rest of the entry is padding)
+    uint32_t ew[LW];
 #pragma unroll
-    for (int i = 0; i < ED_U_ENTRY_WORDS / 4; ++i) {
+    for (int i = 0; i < LW / 4; ++i) {
       const uint4 v = e4[i];
       ew[4 * i] = v.x; ew[4 * i + 1] = v.y; ew[4 * i + 2] = v.z; ew[4 * i + 3] = v.w;
     }
