@@ -104,14 +104,14 @@ WORKLOADS = {
 # read from inside this process, so the figure is the committed measurement of this very
 # workload, not a live one; null where no profile has been taken.
 MEASURED_TRAFFIC = {
-    "p256r1_var_2^20": {"bytes": 2 * (7523101514 + 96229988) + 3672627365 + 103818322,
-                        "fetch_raw": 7523101514 + 96229988, "write": 3672627365 + 103818322,
+    "p256r1_var_2^20": {"bytes": 2 * (6800172443 + 93819216) + 3654147990 + 70297040,
+                        "fetch_raw": 6800172443 + 93819216, "write": 3654147990 + 70297040,
                         "source": "profiles/r01_p256r1_var_u29.json"},
-    "ed25519_base_2^20": {"bytes": 2 * (24184522 + 94970282) + 101712320 + 103857045,
-                          "fetch_raw": 24184522 + 94970282, "write": 101712320 + 103857045,
+    "ed25519_base_2^20": {"bytes": 2 * (1114466784 + 95245696) + 101870378 + 103888809,
+                          "fetch_raw": 1114466784 + 95245696, "write": 101870378 + 103888809,
                           "source": "profiles/r01_ed25519_base.json"},
-    "x25519_2^20": {"bytes": 2 * (31290340 + 92848283) + 101712128 + 70254601,
-                    "fetch_raw": 31290340 + 92848283, "write": 101712128 + 70254601,
+    "x25519_2^20": {"bytes": 2 * (31276132 + 92950162) + 101712091 + 70254592,
+                    "fetch_raw": 31276132 + 92950162, "write": 101712091 + 70254592,
                     "source": "profiles/r01_x25519.json"},
 }
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -329,7 +329,8 @@ def main():
                          "kernel_ms": kernel_ms, "alg_bytes_per_unit": alg_bytes,
                          "alg_bytes_per_launch": alg_bytes * n,
                          "note": "integer-VALU bound path, see valu; traffic above the algorithmic bytes is "
-                                 "the per-lane window table of the variable-base ladder (DESIGN.md §6)"},
+                                 "the per-lane window table of the variable-base ladder / the random reads of the "
+                                 "16-bit-window comb table of the fixed-base path (DESIGN.md §6)"},
             "valu": None if args.variant != "default" else {"bound": "integer multiplier issue (v_mad_u64_u32; + v_addc_co_u32 in saturated kernels)",
                      "achieved": mul_rate / 1e12, "unit": "T limb-products/s",
                      "frac": valu_frac,
