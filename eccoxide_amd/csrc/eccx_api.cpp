@@ -396,7 +396,7 @@ int eccx_scalarmul_base_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_sc
   hipStream_t s = static_cast<hipStream_t>(stream);  // NULL = HIP's default stream
   size_t need = (n + eccx::LAUNCH_WG - 1) / eccx::LAUNCH_WG;
   int grid = (int)std::max<size_t>(1, std::min(need, (size_t)ctx->cus * 8));
-  // default: 8-bit windows over the engine's own wide table (the 4-bit comb of the reference's
+  // default: 16-bit windows over the engine's own wide table (the 4-bit comb of the reference's
   // layout stays reachable through ECCX_MIRROR_REFERENCE / ECCX_TABLE_IN_LDS / ECCX_TABLE_IN_L2)
   if (!d_proj && !(opts & (ECCX_MIRROR_REFERENCE | ECCX_TABLE_IN_LDS | ECCX_TABLE_IN_L2)) && ops->base_unsat &&
       ctx->comb_u[curve]) {
@@ -499,7 +499,7 @@ int eccx_double_scalarmul_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_
   if (!d_u1 || !d_u2 || !d_q || !d_out || !d_flags) return ECCX_ERR_ARG;
   if (!ops->var_fused || !ops->to_affine_var) return ECCX_ERR_ARG;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  // one kernel: the ladder for u2*Q, then the 8-bit comb of u1*G onto the same point
+  // one kernel: the ladder for u2*Q, then the 16-bit comb of u1*G onto the same point
   int rc = ensure_comb(ctx, curve, ops);
   if (rc) return rc;
   if (!ctx->comb_u[curve]) return ECCX_ERR_HIP;

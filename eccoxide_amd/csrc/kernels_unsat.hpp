@@ -6,7 +6,7 @@
 //       +-d*P.  The reference's fixed 4-bit unsigned window (src/curve/projective.rs:871-896)
 //       needs 2*SB additions, this needs ceil((8*SB + 1)/5); k*P is the same point either way.
 //       <CU, true> is the fused double-scalar form u1*G + u2*Q.
-//   k_scalarmul_base_unsat<CU>     mul_base as an 8-bit-window comb over the engine's own table.
+//   k_scalarmul_base_unsat<CU>     mul_base as a 16-bit-window comb over the engine's own table.
 //   k_ed_scalarmul_{var,base}_unsat, k_x25519_ladder_unsat   the edwards25519 / curve25519 forms.
 //
 // The Jacobian addition is not complete: the cases it misses are patched per lane after the
@@ -219,7 +219,7 @@ template <class CU>
 ECCX_DEV void ucomb_accumulate(UJac<CU>& q, const uint8_t* __restrict__ k, const uint32_t* __restrict__ table);
 
 // FUSED: the double-scalar "verify shape" u1*G + u2*Q (src/protocol/ecdsa.rs:215) in one pass:
-// after the ladder has produced u2*Q in Jacobian form, the 8-bit-window comb of u1*G is
+// after the ladder has produced u2*Q in Jacobian form, the 16-bit-window comb of u1*G is
 // accumulated onto the same point (base_scalars, utable as for k_scalarmul_base_unsat), so
 // there is one normalisation and no intermediate affine points.
 template <class CU, bool FUSED = false>
@@ -604,7 +604,7 @@ __global__ void __launch_bounds__(WG, 4) k_x25519_ladder_unsat(size_t n, const u
   }
 }
 
-// ---- edwards25519 fixed base, 8-bit windows, unsaturated field ------------------------------
+// ---- edwards25519 fixed base, 16-bit windows, unsaturated field ------------------------------
 // The reference's mul_base (curve25519.rs:840-851) adds one table entry per 4-bit window; k*B
 // does not depend on the window width, so the default path uses 16-bit windows -- entry (w, d) =
 // d * 2^(16 w) * B as the triple (y - x, y + x, 2d*x*y), d = 0 being the neutral (1, 1, 0) -- from a
@@ -632,7 +632,7 @@ ECCX_DEV void ued_add_niels(U<CU, 1, 3>& qx, U<CU, 1, 3>& qy, U<CU, 1, 3>& qz, U
   qt = u_fit<1, 3>(u_mul(e, h));
 }
 
-// q += sum over the bytes of k of table[(w, byte)] (the 8-bit-window comb; complete additions)
+// q += sum over the 16-bit windows of k of table[(w, digit)] (complete additions)
 template <class CU>
 ECCX_DEV void ued_comb_accumulate(U<CU, 1, 3>& qx, U<CU, 1, 3>& qy, U<CU, 1, 3>& qz, U<CU, 1, 3>& qt,
                                   const uint8_t* __restrict__ k, const uint32_t* __restrict__ table) {
@@ -802,7 +802,7 @@ ECCX_DEV void ued_row_load(UEdCached<CU>& c, const uint32_t* __restrict__ row) {
 }
 
 // FUSED: the verify shape [u1]B + [u2]A ([u1]B - [u2]A with OPT_NEGATE_B; src/protocol/ed25519.rs:145)
-// in one pass: the ladder keeps T through its additions and the 8-bit comb of u1*B is accumulated
+// in one pass: the ladder keeps T through its additions and the 16-bit comb of u1*B is accumulated
 // onto its result (base_scalars, utable as for k_ed_scalarmul_base_unsat).
 template <class CU, bool FUSED = false>
 __global__ void __launch_bounds__(WG, 4) k_ed_scalarmul_var_unsat(size_t n, const uint8_t* __restrict__ scalars,

@@ -140,7 +140,7 @@ int eccx_point_add(eccx_ctx* ctx, int curve, size_t n, const uint8_t* a, const u
  * The batched form of ECDSA verification's u1*G + u2*Q (src/protocol/ecdsa.rs:215) and of
  * Ed25519's [s]B - [k]A (src/protocol/ed25519.rs:145; the reference uses the variable-time
  * double_scalar_mul_base_vartime, src/curve/curve25519.rs:1157-1183 -- same point).  ONE kernel
- * per curve: Weierstrass, the variable-base ladder for u2*Q followed by the 8-bit-window comb of u1*G
+ * per curve: Weierstrass, the variable-base ladder for u2*Q followed by the 16-bit-window comb of u1*G
  * accumulated onto the same Jacobian point, one normalisation; edwards25519 likewise with the
  * complete extended-coordinate additions.
  *   u1, u2 : n x SB scalars      q : n x 2FB affine points      out, flags: as above
