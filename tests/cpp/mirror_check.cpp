@@ -48,6 +48,17 @@ int main() {
     auto zero = base.sub(eng, var).to_affine();
     for (size_t i = 0; i < n; ++i)
       if (!zero.is_infinity(i)) { std::printf("FAIL: P - P is not infinity at %zu\n", i); return 1; }
+    // verify shape: k*G + k*G == (2k)*G == dbl(k*G), and k*G - k*G is infinity
+    auto both = gen.mul_add_base(eng, scalars, scalars).to_affine();
+    auto twice = base.dbl(eng).to_affine();
+    auto none = gen.mul_add_base(eng, scalars, scalars, /*subtract=*/true).to_affine();
+    for (size_t i = 0; i < n; ++i) {
+      if (both.is_infinity(i) != twice.is_infinity(i) || std::memcmp(both.x(i), twice.x(i), 64)) {
+        std::printf("FAIL: k*G + k*G != 2(k*G) at %zu\n", i);
+        return 1;
+      }
+      if (!none.is_infinity(i)) { std::printf("FAIL: k*G - k*G is not infinity at %zu\n", i); return 1; }
+    }
     std::puts("mirror_check ok");
     return 0;
   } catch (const std::exception& e) {
