@@ -203,6 +203,29 @@ def test_edwards_window_ladder_on_torsion_points(engine, oracle):
     assert len(set(tors[i:i + 64] for i in range(0, len(tors), 64))) >= 4  # several distinct torsion points
 
 
+@pytest.mark.parametrize("curve", ALL)
+def test_default_and_mirror_kernels_agree_on_a_large_batch(engine, oracle, curve):
+    """Two independent arithmetic stacks -- unsaturated limbs + Jacobian/windowed ladders + 16-bit
+    combs (default) and saturated canonical limbs + the reference's complete formulas and 4-bit
+    windows (mirror) -- must produce the same bytes and flags for 2^16 random units, variable and
+    fixed base; a sample is checked against the CPU oracle as well."""
+    import torch
+
+    n = 1 << 16
+    dev = torch.device("cuda", 0)
+    ks = torch.from_numpy(W.random_scalars(curve, n, seed=501)).to(dev)
+    rs = torch.from_numpy(W.random_scalars(curve, n, seed=502)).to(dev)
+    pts, fl = engine.scalarmul_base_t(curve, rs)
+    pts_m, fl_m = engine.scalarmul_base_t(curve, rs, mirror=True)
+    assert torch.equal(pts, pts_m) and torch.equal(fl, fl_m)
+    out, f = engine.scalarmul_var_t(curve, ks, pts)
+    out_m, f_m = engine.scalarmul_var_t(curve, ks, pts, mirror=True)
+    assert torch.equal(out, out_m) and torch.equal(f, f_m)
+    idx = torch.arange(0, n, 257, device=dev)
+    want = oracle.var(curve, ks[idx].cpu().numpy().tobytes(), pts[idx].cpu().numpy().tobytes(), threads=4)
+    assert out[idx].cpu().numpy().tobytes() == want[0] and f[idx].cpu().numpy().tobytes() == want[1]
+
+
 # ---- the reference's own known-answer vectors, on the GPU ---------------------------------
 @pytest.mark.parametrize("curve", ["p256r1", "p384r1", "p521r1"])
 def test_nist_kg_on_gpu(engine, oracle, curve):
