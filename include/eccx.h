@@ -32,10 +32,11 @@
  *     subgroup that equals (k mod n)*P.
  *
  * All functions return 0 on success or a negative ECCX_ERR_* code; none aborts.
- * A context is bound to one GPU; calls on one context are serialised by the caller or
- * issued on different streams (the constant tables are read-only after first use; the
- * variable-base scratch slab is per context, so concurrent variable-base calls need
- * one context each).
+ * A context is bound to one GPU and owns its device scratch (window-table slab, row buffer)
+ * and the fixed-base tables it builds at first use (16-bit-window tables: 84-415 MB per curve
+ * used, once).  Calls on ONE context must not overlap in time -- enqueue them on one stream,
+ * or serialise them; use one context per stream / host thread for concurrency (table
+ * construction is guarded by a mutex; the tables are read-only afterwards).
  */
 #ifndef ECCX_H
 #define ECCX_H
