@@ -83,6 +83,8 @@ def test_edge_scalars(engine, oracle, curve):
     order = W.order(curve)
     top = (1 << 521) - 1 if curve == "p521r1" else (1 << (8 * sb)) - 1
     vals = [0, 1, 2, 15, 16, 17, order - 1, order, order + 1, top, 1 << (8 * sb - 8)]
+    if curve == "p521r1":   # the 66-byte string has 7 bits above the field size: still k*P for the integer k
+        vals += [(1 << 528) - 1, 1 << 527, (1 << 522) + 12345, (1 << 528) - order]
     vals = [v for v in vals if v < (1 << (8 * sb))]
     ks = b"".join(v.to_bytes(sb, "big") for v in vals)
     n = len(vals)
