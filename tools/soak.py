@@ -84,6 +84,20 @@ def main():
             s_out, s_fl = eng.point_add(curve, b_mir.cpu().numpy().tobytes(), v_mir.cpu().numpy().tobytes(),
                                         a_inf=a_inf, b_inf=b_inf, subtract=subtract)
             assert d_out.cpu().numpy().tobytes() == s_out and d_fl.cpu().numpy().tobytes() == s_fl, ("dsm", curve, n, subtract, rounds)
+        # validation: corrupt some bases (off-curve / non-canonical) and require identical rejection
+        # (flag 2, zero bytes) from both stacks and from the fused kernel
+        if rounds % 4 == 0:
+            bad = b_def.clone()
+            sel = torch.rand(n, device=dev) < 0.3
+            bad[sel, rng.randrange(bad.shape[1])] ^= 1 << rng.randrange(8)
+            if rng.random() < 0.5:
+                bad[sel & (torch.rand(n, device=dev) < 0.3)] = 0xFF   # non-canonical coordinates
+            o1, f1 = eng.scalarmul_var_t(curve, k2, bad, validate=True)
+            o2, f2 = eng.scalarmul_var_t(curve, k2, bad, validate=True, mirror=True)
+            assert torch.equal(o1, o2) and torch.equal(f1, f2), ("validate", curve, n, rounds)
+            o3, f3 = eng.double_scalarmul_t(curve, torch.zeros_like(k1), k2, bad, validate=True)
+            rej = f1 == 2
+            assert torch.equal(f3 == 2, rej) and torch.equal(o3[~rej], o1[~rej]) and not bool(o3[rej].any()), ("validate dsm", curve, n, rounds)
         rounds += 1
         units += n
     print(f"soak ok: {rounds} rounds, {units} units per operation, {time.time() - t0:.0f} s")
