@@ -29,9 +29,6 @@ namespace eccx {
 #ifndef ECCX_ENTRY_ALIGN
 #define ECCX_ENTRY_ALIGN 32
 #endif
-#ifndef ECCX_EXP_ROW
-#define ECCX_EXP_ROW(d) (d)
-#endif
 
 template <class CU>
 struct UJac {
@@ -314,7 +311,7 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_var_uns
         bool neg = false;
         if (!building) booth(win, d, neg);
         UEntry<CU> e;
-        uentry_load<CU>(e, row(ECCX_EXP_ROW(d ? d : 1)));
+        uentry_load<CU>(e, row(d ? d : 1));
         const bool q_inf = u_limbs_all_zero(q.z);
         const bool e_skip = (d == 0) || u_limbs_all_zero(e.z);
         UJac<CU> sum;
@@ -332,7 +329,7 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_var_uns
         // registers across the addition -- that is what used to push the body into spilling.
         if (__builtin_amdgcn_ballot_w64(q_inf) != 0) {
           UEntry<CU> e2;
-          const uint32_t* again = row(ECCX_EXP_ROW(d ? d : 1));
+          const uint32_t* again = row(d ? d : 1);
           asm volatile("" : "+v"(again));  // a fresh read: do not keep the first copy alive instead
           uentry_load<CU>(e2, again);
           U<CU, 2, 4> sy;
