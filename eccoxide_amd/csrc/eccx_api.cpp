@@ -45,6 +45,7 @@ struct eccx_ctx {
   int device = 0;
   int cus = 0;
   hipStream_t stream = nullptr;
+  hipStream_t in_stream = nullptr, out_stream = nullptr;  // host-buffer entry points: copies beside the compute
   uint32_t* comb[NCURVES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   uint32_t* comb_u[NCURVES] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // unsaturated-field copies
   std::mutex comb_mu;
@@ -271,15 +272,76 @@ int run_host(eccx_ctx* ctx, int curve, bool base, size_t n, const uint8_t* scala
   TRY_(hipMalloc(&d_f, n));
   if (!base) TRY_(hipMalloc(&d_p, n * pb));
   if (proj) TRY_(hipMalloc(&d_j, n * proj_bytes(ops)));
-  TRY_(hipMemcpyAsync(d_k, scalars, n * sb, hipMemcpyHostToDevice, ctx->stream));
-  if (!base) TRY_(hipMemcpyAsync(d_p, points, n * pb, hipMemcpyHostToDevice, ctx->stream));
-  if (base) rc = eccx_scalarmul_base_dev(ctx, curve, n, d_k, d_o, d_f, d_j, opts, ctx->stream);
-  else rc = eccx_scalarmul_var_dev(ctx, curve, n, d_k, d_p, d_o, d_f, d_j, opts, ctx->stream);
-  if (rc) { cleanup(); return rc; }
-  TRY_(hipMemcpyAsync(out, d_o, n * pb, hipMemcpyDeviceToHost, ctx->stream));
-  TRY_(hipMemcpyAsync(flags, d_f, n, hipMemcpyDeviceToHost, ctx->stream));
-  if (proj) TRY_(hipMemcpyAsync(proj, d_j, n * proj_bytes(ops), hipMemcpyDeviceToHost, ctx->stream));
-  TRY_(hipStreamSynchronize(ctx->stream));
+  // Large batches go through in chunks so that the PCIe copies of chunk i+1 (in) and i-1 (out) run
+  // beside the kernels of chunk i: three streams, events between them.  The host buffers are
+  // pageable, so each copy call returns when its data has been staged; the kernels it overlaps
+  // with are already enqueued.
+  // (variable base only: measured 20.8 -> 19.3 ms for 2^20 p256 units; the fixed-base kernels are
+  // shorter than their copies and lose to the per-chunk launch costs: 3.4 -> 4.5 ms)
+  const size_t nchunks = (!proj && !base && n >= ((size_t)1 << 17)) ? 4 : 1;
+  const size_t step = ((n + nchunks - 1) / nchunks + 4095) / 4096 * 4096;
+  // a single chunk keeps everything on the compute stream (crossing streams costs ~1 ms of idle gaps)
+  hipStream_t s_in = nchunks > 1 ? ctx->in_stream : ctx->stream;
+  hipStream_t s_out = nchunks > 1 ? ctx->out_stream : ctx->stream;
+  std::vector<hipEvent_t> evs;
+  auto new_event = [&](hipEvent_t* e) {
+    hipError_t r = hipEventCreateWithFlags(e, hipEventDisableTiming);
+    if (r == hipSuccess) evs.push_back(*e);
+    return r;
+  };
+  auto drop_events = [&]() {
+    for (auto e : evs) (void)hipEventDestroy(e);
+    evs.clear();
+  };
+  auto cleanup_all = [&]() {
+    (void)hipStreamSynchronize(s_in);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(s_out);
+    drop_events();
+    cleanup();
+  };
+#define TRY2_(call)                                 \
+  do {                                              \
+    hipError_t e_ = (call);                         \
+    if (e_ != hipSuccess) {                         \
+      ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); \
+      cleanup_all();                                \
+      return e_ == hipErrorOutOfMemory ? ECCX_ERR_NOMEM : ECCX_ERR_HIP; \
+    }                                               \
+  } while (0)
+  hipEvent_t prev_done = nullptr;
+  size_t prev_lo = 0, prev_cnt = 0;
+  auto copy_out = [&](size_t lo, size_t cnt, hipEvent_t done) -> hipError_t {
+    hipError_t r = hipStreamWaitEvent(s_out, done, 0);
+    if (r == hipSuccess) r = hipMemcpyAsync(out + lo * pb, d_o + lo * pb, cnt * pb, hipMemcpyDeviceToHost, s_out);
+    if (r == hipSuccess) r = hipMemcpyAsync(flags + lo, d_f + lo, cnt, hipMemcpyDeviceToHost, s_out);
+    return r;
+  };
+  for (size_t lo = 0; lo < n; lo += step) {
+    const size_t cnt = std::min(step, n - lo);
+    TRY2_(hipMemcpyAsync(d_k + lo * sb, scalars + lo * sb, cnt * sb, hipMemcpyHostToDevice, s_in));
+    if (!base) TRY2_(hipMemcpyAsync(d_p + lo * pb, points + lo * pb, cnt * pb, hipMemcpyHostToDevice, s_in));
+    hipEvent_t in_ready, done;
+    TRY2_(new_event(&in_ready));
+    TRY2_(hipEventRecord(in_ready, s_in));
+    TRY2_(hipStreamWaitEvent(ctx->stream, in_ready, 0));
+    if (base) rc = eccx_scalarmul_base_dev(ctx, curve, cnt, d_k + lo * sb, d_o + lo * pb, d_f + lo, d_j, opts, ctx->stream);
+    else rc = eccx_scalarmul_var_dev(ctx, curve, cnt, d_k + lo * sb, d_p + lo * pb, d_o + lo * pb, d_f + lo, d_j, opts, ctx->stream);
+    if (rc) { cleanup_all(); return rc; }
+    TRY2_(new_event(&done));
+    TRY2_(hipEventRecord(done, ctx->stream));
+    if (prev_done) TRY2_(copy_out(prev_lo, prev_cnt, prev_done));
+    prev_done = done; prev_lo = lo; prev_cnt = cnt;
+  }
+  TRY2_(copy_out(prev_lo, prev_cnt, prev_done));
+  if (proj) {
+    TRY2_(hipStreamWaitEvent(s_out, prev_done, 0));
+    TRY2_(hipMemcpyAsync(proj, d_j, n * proj_bytes(ops), hipMemcpyDeviceToHost, s_out));
+  }
+  TRY2_(hipStreamSynchronize(s_out));
+  TRY2_(hipStreamSynchronize(ctx->stream));
+  drop_events();
+#undef TRY2_
 #undef TRY_
   cleanup();
   return ECCX_OK;
@@ -333,7 +395,11 @@ int eccx_init(int device, eccx_ctx** out_ctx) {
   if (!ctx) return ECCX_ERR_NOMEM;
   ctx->device = device;
   ctx->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->in_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->out_stream, hipStreamNonBlocking) != hipSuccess) {
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->in_stream) (void)hipStreamDestroy(ctx->in_stream);
     delete ctx;
     return ECCX_ERR_HIP;
   }
@@ -352,6 +418,8 @@ void eccx_shutdown(eccx_ctx* ctx) {
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->jac) (void)hipFree(ctx->jac);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  if (ctx->in_stream) (void)hipStreamDestroy(ctx->in_stream);
+  if (ctx->out_stream) (void)hipStreamDestroy(ctx->out_stream);
   delete ctx;
 }
 
