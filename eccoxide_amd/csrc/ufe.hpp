@@ -7,11 +7,13 @@
 // is ONE v_mad_u64_u32, squares really cost half the cross products, additions are N
 // independent v_add_u32 and there is no conditional subtraction.
 //
-// Three kinds of field (C::KIND), all reproducing the reference's values modulo p only
+// Four kinds of field (C::KIND), all reproducing the reference's values modulo p only
 // (canonical bytes are produced at the very end, u_to_canonical):
 //   0  Montgomery, R = 2^(B*N), p = -1 mod 2^B: the Montgomery factor m is the low limb of
 //      the accumulator itself and "+ m*p" becomes "drop that limb, + m*(p+1)"; p + 1 has few
-//      non-zero digits for the NIST primes (P-256: 4 of 9)     (src/curve/fiat/p256_64.rs, p384_64.rs)
+//      non-zero digits for P-256 (4 of 9); for P-384 (12 of 14 digits but 4 signed powers of two)
+//      it is added as signed shifted copies of m into signed columns (SPARSE_*)
+//                                                     (src/curve/fiat/p256_64.rs, p384_64.rs)
 //   1  Montgomery, general p (BLS12-381): m = acc * (-p^-1) mod 2^B   (src/curve/fiat/bls12_381_*.rs)
 //   2  p = 2^k - 1 (P-521), plain representation: the wrapped half of the product is
 //      accumulated into the same columns with weight 2^(B*N - k)          (src/curve/fiat/p521_64.rs)
@@ -32,8 +34,9 @@
 //   add         K1+K2 <= KMAX (limbs below 2^32), V1+V2
 //   sub         a + BIAS - b with BIAS = 4p spread so no limb borrows; b tight and < 3p;
 //               returns K1+2, V1+4
-//   reduce      one signed carry chain that also takes off q*p, q ~ value / p estimated from the
-//               top limbs: returns exact tight digits of a value < 3p
+//   reduce      one carry chain that also takes off q*p, q ~ value / p estimated from the top
+//               limbs (shifted copies of q for the Solinas primes, 32-bit unsigned for kinds 2
+//               and 3, signed 64-bit otherwise): returns exact tight digits of a value < 3p
 #pragma once
 #include "fe.hpp"
 
