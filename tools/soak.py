@@ -3,7 +3,7 @@
 combs, fused double-scalar) against the reference-mirroring kernels (saturated canonical limbs,
 complete formulas, 4-bit windows) on random batches of random sizes, all curves.
 
-    python tools/soak.py [seconds]
+    python tools/soak.py [seconds] [seed]
 
 Scalars mix uniform values with sparse / edge patterns (few set bits, all-ones runs, values around
 the group order) to provoke the special cases of the Jacobian ladder and the combs.  Exits non-zero
@@ -52,10 +52,10 @@ def scalars(curve, n, rng):
 
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-    rng = random.Random(20260401)
+    rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 20260401)
     dev = torch.device("cuda", 0)
     eng = E.Engine(0)
-    t0 = time.time()
+    t0 = last = time.time()
     rounds = units = 0
     while time.time() - t0 < budget:
         curve = rng.choice(CURVES)
@@ -100,6 +100,9 @@ def main():
             assert torch.equal(f3 == 2, rej) and torch.equal(o3[~rej], o1[~rej]) and not bool(o3[rej].any()), ("validate dsm", curve, n, rounds)
         rounds += 1
         units += n
+        if time.time() - last > 30:   # a heartbeat: long silent runs look hung to a job runner
+            last = time.time()
+            print(f"  {rounds} rounds, {units} units, {last - t0:.0f} s", flush=True)
     print(f"soak ok: {rounds} rounds, {units} units per operation, {time.time() - t0:.0f} s")
 
 
