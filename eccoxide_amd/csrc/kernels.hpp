@@ -1,25 +1,16 @@
-// Batched scalar-multiplication kernels for gfx950: one (scalar, base) pair per
-// lane, 256-thread workgroups (4 wavefronts), no cross-lane communication.
+// Reference-mirroring kernels on saturated canonical limbs (fe.hpp) and the shared result tails:
+// one (scalar, base) pair per lane, 256-thread workgroups, no cross-lane communication.
 //
-//   k_scalarmul_var<C>   &Point * &Scalar           curve_macros.rs:321-327 -> :47-49 / :103-105
-//                        -> scale_{am3,a0}_ct        projective.rs:905-918
-//                        -> scalar_mul_fixed_window  projective.rs:871-896 / :842-867
 //   k_scalarmul_base<C>  Point::mul_base             curve_macros.rs:55-63 / :111-119
 //                        -> mul_base_table_{am3,a0}  projective.rs:965-981 / :945-961
 //   k_ed_scalarmul_var   curve25519::Point::scale    curve25519.rs:746-762 (double-and-add)
 //   k_ed_scalarmul_base  curve25519::Point::mul_base curve25519.rs:840-851
+//   k_point_add, k_ed_point_add                      the group law on batches
 //   tails                to_affine_ct                projective.rs:655-682 ; curve25519.rs:663-666
 //
-// The per-lane 16-entry window table of the variable-base ladder (projective.rs:875-881)
-// does not fit LDS at a useful occupancy (16 x 96 B x 64 lanes = 96 KiB per wavefront
-// for P-256), so it lives in an HBM scratch slab, one row of W words per (entry, lane),
-// read back with 16-byte loads; it is private to the lane, so no synchronisation.
-// Lookups index the table directly: the reference scans all 16 entries for
-// constant-time behaviour (projective.rs:427-434), which changes timing, not values.
-//
-// The ladder is written as ONE loop whose body holds a single copy of the doubling
-// and a single copy of the addition (table build and main loop share them), chosen by
-// wave-uniform control flow, so the whole kernel stays inside the instruction cache.
+// The reference-mirroring Weierstrass LADDER (&Point * &Scalar, projective.rs:871-896) is
+// k_scalarmul_var_mirror_unsat in kernels_unsat.hpp; it ends in store_result below.  The
+// default kernels are in kernels_unsat.hpp as well.
 #pragma once
 #include "curve.hpp"
 #include "inv_gcd.hpp"
@@ -133,83 +124,6 @@ ECCX_DEV void store_result(size_t idx, const Pt<C>& q, bool rejected, uint8_t* _
     fe_from_mont<C>(t, q.y); fe_store_be<C>(pr + FB, t);
     fe_from_mont<C>(t, q.z); fe_store_be<C>(pr + 2 * FB, t);
   }
-}
-
-template <class C>
-__global__ void __launch_bounds__(WG) k_scalarmul_var(size_t n, const uint8_t* __restrict__ scalars,
-                                                      const uint8_t* __restrict__ points, uint8_t* __restrict__ out,
-                                                      uint8_t* __restrict__ flags, uint8_t* __restrict__ proj,
-                                                      uint32_t* __restrict__ scratch, uint32_t opts) {
-  constexpr int L = C::L;
-  constexpr int FB = C::FB;
-  constexpr int SB = C::SB;
-  constexpr int W = row_words<L>();
-  // scratch slab of this lane, reused across the grid-stride loop:
-  // [workgroup][entry 0..15][thread 0..255][W words]
-  uint32_t* slab = scratch + ((size_t)blockIdx.x * 16 * WG + threadIdx.x) * (size_t)W;
-  auto row = [&](uint32_t e) { return slab + (size_t)e * WG * W; };
-  for (size_t base = (size_t)blockIdx.x * WG; base < n; base += (size_t)gridDim.x * WG) {
-  const size_t gid = base + threadIdx.x;
-  const bool active = gid < n;
-  const size_t idx = active ? gid : n - 1;  // idle lanes shadow the last unit, never store
-
-  Pt<C> q;
-  bool rejected = false;
-  if (opts & OPT_BASE_IS_GENERATOR) {
-    fe_set<C>(q.x, C::GX);
-    fe_set<C>(q.y, C::GY);
-  } else {
-    Fe<L> rx, ry;
-    fe_load_be<C>(rx, points + idx * (size_t)(2 * FB));
-    fe_load_be<C>(ry, points + idx * (size_t)(2 * FB) + FB);
-    fe_to_mont<C>(q.x, rx);
-    fe_to_mont<C>(q.y, ry);
-    if (opts & OPT_VALIDATE) {
-      rejected = !(fe_is_canonical<C>(rx) && fe_is_canonical<C>(ry) && on_curve<C>(q.x, q.y));
-    }
-  }
-  fe_set<C>(q.z, C::ONE);
-  {
-    Pt<C> inf;
-    pt_set_inf<C>(inf);
-    row_store<C>(row(0), inf);
-    row_store<C>(row(1), q);
-  }
-  const uint8_t* __restrict__ k = scalars + idx * (size_t)SB;
-
-  // steps 0..13 build table[2..15]; then NW windows of (4 doublings + 1 addition)
-  constexpr int NW = 2 * SB;
-  constexpr int NSTEPS = 14 + 5 * NW;
-  int win = 0, sub = 0;
-  for (int s = 0; s < NSTEPS; ++s) {
-    const bool building = s < 14;
-    bool do_dbl;
-    if (building) {
-      do_dbl = (s == 0);
-    } else {
-      if (s == 14) pt_set_inf<C>(q);
-      do_dbl = sub < 4;
-    }
-    if (do_dbl) {
-      pt_dbl<C>(q, q);
-    } else {
-      uint32_t e = 1;
-      if (!building) {
-        uint32_t byte = k[win >> 1];
-        e = (win & 1) ? (byte & 0x0f) : (byte >> 4);  // high nibble first (projective.rs:885)
-      }
-      Pt<C> sel;
-      row_load<C>(sel, row(e));
-      pt_add<C>(q, q, sel);
-    }
-    if (building) {
-      row_store<C>(row(s + 2), q);
-    } else {
-      if (++sub == 5) { sub = 0; ++win; }
-    }
-  }
-  if (active) store_result<C>(idx, q, rejected, out, flags, proj, opts);
-  }  // grid-stride
 }
 
 // Fixed-base comb: table[w][d] (d = 1..15) = d * 16^w * G as affine Montgomery limbs,

@@ -924,4 +924,216 @@ __global__ void __launch_bounds__(WG, 4) k_ed_scalarmul_var_unsat(size_t n, cons
   }
 }
 
+// ---- reference-mirroring variable-base ladder on the unsaturated field ----------------------
+// Same algorithm, operation for operation, as k_scalarmul_var (kernels.hpp): the reference's
+// scalar_mul_fixed_window_{am3,a0} (src/curve/projective.rs:871-896 / :842-867) -- table d*P,
+// d = 0..15, then per nibble (high first) 4 doublings, lookup, 1 complete addition -- with the
+// Renes-Costello-Batina formulas add_different_{am3,a0} (:340-423 / :268-338) and double_{am3,a0}
+// (:586-646 / :544-583) in homogeneous coordinates.  Only the limb representation differs, so the
+// un-normalised (X : Y : Z) it ends with are the reference's, residue for residue; the result is
+// handed to the saturated tail (store_result) as canonical Montgomery limbs.
+template <class CU>
+struct UPt {
+  U<CU, 1, 3> x, y, z;
+};
+
+template <class CU>
+ECCX_DEV void upt_add(UPt<CU>& r, const UPt<CU>& p, const UPt<CU>& q) {
+  auto t0 = u_mul(p.x, q.x);
+  auto t1 = u_mul(p.y, q.y);
+  auto t2 = u_mul(p.z, q.z);
+  auto t3 = u_sub(u_mul(u_add(p.x, p.y), u_add(q.x, q.y)), u_add(t0, t1));
+  auto t4 = u_sub(u_mul(u_add(p.y, p.z), u_add(q.y, q.z)), u_add(t1, t2));
+  auto y3 = u_sub(u_mul(u_add(p.x, p.z), u_add(q.x, q.z)), u_add(t0, t2));
+  if constexpr (CU::Sat::A0) {
+    auto t0x3 = u_add(u_add(t0, t0), t0);
+    auto t2b = u_mul_k<CU>(t2, CU::CB3);
+    auto z3 = u_add(t1, t2b);
+    auto t1b = u_sub(t1, t2b);
+    auto y3b = u_mul_k<CU>(y3, CU::CB3);
+    auto x3 = u_sub(u_mul(t3, t1b), u_mul(t4, y3b));
+    auto y3c = u_add(u_mul(t1b, z3), u_mul(y3b, t0x3));
+    auto z3b = u_add(u_mul(z3, t4), u_mul(t0x3, t3));
+    r.x = u_fit<1, 3>(x3); r.y = u_fit<1, 3>(y3c); r.z = u_fit<1, 3>(z3b);
+  } else {
+    auto x3a = u_sub(y3, u_mul_k<CU>(t2, CU::CB));
+    auto x3b = u_add(u_add(x3a, x3a), x3a);
+    auto z3 = u_sub(t1, x3b);
+    auto x3 = u_add(t1, x3b);
+    auto t2x3 = u_add(u_add(t2, t2), t2);
+    auto y3a = u_sub(u_sub(u_mul_k<CU>(y3, CU::CB), t2x3), t0);
+    auto y3b = u_add(u_add(y3a, y3a), y3a);
+    auto t0b = u_sub(u_add(u_add(t0, t0), t0), t2x3);
+    auto x3f = u_sub(u_mul(t3, x3), u_mul(t4, y3b));
+    auto y3f = u_add(u_mul(x3, z3), u_mul(t0b, y3b));
+    auto z3f = u_add(u_mul(t4, z3), u_mul(t3, t0b));
+    r.x = u_fit<1, 3>(x3f); r.y = u_fit<1, 3>(y3f); r.z = u_fit<1, 3>(z3f);
+  }
+}
+
+template <class CU>
+ECCX_DEV void upt_dbl(UPt<CU>& r, const UPt<CU>& p) {
+  if constexpr (CU::Sat::A0) {
+    auto t0 = u_sqr(p.y);
+    auto z2 = u_add(t0, t0);
+    auto z4 = u_add(z2, z2);
+    auto z8 = u_add(z4, z4);
+    auto t1 = u_mul(p.y, p.z);
+    auto t2 = u_mul_k<CU>(u_sqr(p.z), CU::CB3);
+    auto x3a = u_mul(t2, z8);
+    auto y3a = u_add(t0, t2);
+    auto z3 = u_mul(t1, z8);
+    auto t2x3 = u_add(u_add(t2, t2), t2);
+    auto t0b = u_sub(t0, t2x3);
+    auto y3 = u_add(x3a, u_mul(t0b, y3a));
+    auto x3m = u_mul(t0b, u_mul(p.x, p.y));
+    r.x = u_fit<1, 3>(u_add(x3m, x3m)); r.y = u_fit<1, 3>(y3); r.z = u_fit<1, 3>(z3);
+  } else {
+    auto t0 = u_sqr(p.x);
+    auto t1 = u_sqr(p.y);
+    auto t2 = u_sqr(p.z);
+    auto xy = u_mul(p.x, p.y);
+    auto t3 = u_add(xy, xy);
+    auto xz = u_mul(p.x, p.z);
+    auto z3a = u_add(xz, xz);
+    auto y3a = u_sub(u_mul_k<CU>(t2, CU::CB), z3a);
+    auto y3b = u_add(u_add(y3a, y3a), y3a);
+    auto x3a = u_sub(t1, y3b);
+    auto y3c = u_add(t1, y3b);
+    auto y3d = u_mul(x3a, y3c);
+    auto x3b = u_mul(x3a, t3);
+    auto t2x3 = u_add(u_add(t2, t2), t2);
+    auto z3b = u_sub(u_sub(u_mul_k<CU>(z3a, CU::CB), t2x3), t0);
+    auto z3c = u_add(u_add(z3b, z3b), z3b);
+    auto t0b = u_sub(u_add(u_add(t0, t0), t0), t2x3);
+    auto y3 = u_add(y3d, u_mul(t0b, z3c));
+    auto yz = u_mul(p.y, p.z);
+    auto t0c = u_add(yz, yz);
+    auto x3 = u_sub(x3b, u_mul(t0c, z3c));
+    auto z3d = u_mul(t0c, t1);
+    auto z3e = u_add(z3d, z3d);
+    r.x = u_fit<1, 3>(x3); r.y = u_fit<1, 3>(y3); r.z = u_fit<1, 3>(u_add(z3e, z3e));
+  }
+}
+
+template <class CU>
+constexpr int urow3_words() { return ((3 * CU::N + 3) / 4) * 4; }
+template <class CU>
+ECCX_DEV void upt_store(uint32_t* __restrict__ row, const UPt<CU>& p) {
+  constexpr int N = CU::N;
+  constexpr int W = urow3_words<CU>();
+  uint32_t w[W];
+#pragma unroll
+  for (int i = 0; i < W; ++i) w[i] = i < N ? p.x.v[i] : (i < 2 * N ? p.y.v[i - N] : (i < 3 * N ? p.z.v[i - 2 * N] : 0u));
+  uint4* dst = reinterpret_cast<uint4*>(row);
+#pragma unroll
+  for (int i = 0; i < W / 4; ++i) dst[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+template <class CU>
+ECCX_DEV void upt_load(UPt<CU>& p, const uint32_t* __restrict__ row) {
+  constexpr int N = CU::N;
+  constexpr int W = urow3_words<CU>();
+  uint32_t w[W];
+  const uint4* src = reinterpret_cast<const uint4*>(row);
+#pragma unroll
+  for (int i = 0; i < W / 4; ++i) {
+    const uint4 q = src[i];
+    w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) { p.x.v[i] = w[i]; p.y.v[i] = w[N + i]; p.z.v[i] = w[2 * N + i]; }
+}
+
+template <class CU>
+__global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_var_mirror_unsat(
+    size_t n, const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ points, uint8_t* __restrict__ out,
+    uint8_t* __restrict__ flags, uint8_t* __restrict__ proj, uint32_t* __restrict__ scratch, uint32_t opts) {
+  using CS = typename CU::Sat;
+  constexpr int L = CS::L;
+  constexpr int FB = CS::FB;
+  constexpr int SB = CS::SB;
+  constexpr int W = urow3_words<CU>();
+  // [workgroup][entry 0..15][thread 0..255][W words]
+  uint32_t* slab = scratch + ((size_t)blockIdx.x * 16 * WG + threadIdx.x) * (size_t)W;
+  auto row = [&](uint32_t e) { return slab + (size_t)e * WG * W; };
+  for (size_t base = (size_t)blockIdx.x * WG; base < n; base += (size_t)gridDim.x * WG) {
+    const size_t gid = base + threadIdx.x;
+    const bool active = gid < n;
+    const size_t idx = active ? gid : n - 1;
+    U<CU, 1, 3> one, zero;
+    u_set_zero(zero);
+#pragma unroll
+    for (int i = 0; i < CU::N; ++i) one.v[i] = CU::ONE[i];
+    UPt<CU> q;
+    bool rejected = false;
+    if (opts & OPT_BASE_IS_GENERATOR) {
+#pragma unroll
+      for (int i = 0; i < CU::N; ++i) { q.x.v[i] = CU::GX[i]; q.y.v[i] = CU::GY[i]; }
+    } else {
+      Fe<L> rx, ry;
+      fe_load_be<CS>(rx, points + idx * (size_t)(2 * FB));
+      fe_load_be<CS>(ry, points + idx * (size_t)(2 * FB) + FB);
+      if (opts & OPT_VALIDATE) {
+        Fe<L> mx, my;
+        fe_to_mont<CS>(mx, rx);
+        fe_to_mont<CS>(my, ry);
+        rejected = !(fe_is_canonical<CS>(rx) && fe_is_canonical<CS>(ry) && on_curve<CS>(mx, my));
+      }
+      q.x = u_as<1, 3>(u_to_mont<CU>(rx));
+      q.y = u_as<1, 3>(u_to_mont<CU>(ry));
+    }
+    q.z = one;
+    {
+      UPt<CU> inf;  // (0 : 1 : 0), projective.rs:152-156
+      inf.x = zero; inf.y = one; inf.z = zero;
+      upt_store<CU>(row(0), inf);
+      upt_store<CU>(row(1), q);
+    }
+    const uint8_t* __restrict__ k = scalars + idx * (size_t)SB;
+    // steps 0..13 build table[2..15]; then 2*SB windows of (4 doublings + 1 addition)
+    constexpr int NW = 2 * SB;
+    constexpr int NSTEPS = 14 + 5 * NW;
+    int win = 0, sub = 0;
+    for (int s = 0; s < NSTEPS; ++s) {
+      const bool building = s < 14;
+      bool do_dbl;
+      if (building) {
+        do_dbl = (s == 0);
+      } else {
+        if (s == 14) { q.x = zero; q.y = one; q.z = zero; }
+        do_dbl = sub < 4;
+      }
+      if (do_dbl) {
+        UPt<CU> t;
+        upt_dbl<CU>(t, q);
+        q = t;
+      } else {
+        uint32_t e = 1;
+        if (!building) {
+          const uint32_t byte = k[win >> 1];
+          e = (win & 1) ? (byte & 0x0f) : (byte >> 4);  // high nibble first (projective.rs:885)
+        }
+        UPt<CU> sel, t;
+        upt_load<CU>(sel, row(e));
+        upt_add<CU>(t, q, sel);
+        q = t;
+      }
+      if (building) {
+        upt_store<CU>(row(s + 2), q);
+      } else {
+        if (++sub == 5) { sub = 0; ++win; }
+      }
+    }
+    if (active) {
+      // the saturated tail expects canonical Montgomery limbs
+      Pt<CS> res;
+      Fe<L> c;
+      u_to_canonical<CU>(c, q.x); fe_to_mont<CS>(res.x, c);
+      u_to_canonical<CU>(c, q.y); fe_to_mont<CS>(res.y, c);
+      u_to_canonical<CU>(c, q.z); fe_to_mont<CS>(res.z, c);
+      store_result<CS>(idx, res, rejected, out, flags, proj, opts);
+    }
+  }
+}
+
 }  // namespace eccx

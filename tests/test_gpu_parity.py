@@ -207,10 +207,11 @@ def test_edwards_window_ladder_on_torsion_points(engine, oracle):
 
 @pytest.mark.parametrize("curve", ALL)
 def test_default_and_mirror_kernels_agree_on_a_large_batch(engine, oracle, curve):
-    """Two independent arithmetic stacks -- unsaturated limbs + Jacobian/windowed ladders + 16-bit
-    combs (default) and saturated canonical limbs + the reference's complete formulas and 4-bit
-    windows (mirror) -- must produce the same bytes and flags for 2^16 random units, variable and
-    fixed base; a sample is checked against the CPU oracle as well."""
+    """Two different routes to the same points -- Jacobian coordinates, signed 5-bit windows and
+    16-bit combs (default) against the reference's complete formulas in homogeneous coordinates,
+    4-bit windows and 4-bit comb on saturated canonical limbs (mirror; its variable-base ladder
+    shares the unsaturated field layer) -- must produce the same bytes and flags for 2^16 random
+    units, variable and fixed base; a sample is checked against the CPU oracle as well."""
     import torch
 
     n = 1 << 16

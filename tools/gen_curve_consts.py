@@ -174,12 +174,13 @@ def main():
         out.append(arr("GY", limbs(gy * R % p, L)))
         out.append("};")
         out.append("")
+    bb = lambda i: (("CB", CURVES[i][2]), ("CB3", 3 * CURVES[i][2] % CURVES[i][1]))   # curve constant b and 3b
     emit_unsat(out, "P256U", "P256", CURVES[0][1], CURVES[0][3], CURVES[0][4], 29, 9, 0,
-               solinas=((224, -1), (192, 1), (96, 1)))
+               solinas=((224, -1), (192, 1), (96, 1)), extra=bb(0))
     emit_unsat(out, "P384U", "P384", CURVES[1][1], CURVES[1][3], CURVES[1][4], 28, 14, 0,
-               solinas=((128, -1), (96, -1), (32, 1)), sparse=True)
-    emit_unsat(out, "P521U", "P521", CURVES[2][1], CURVES[2][3], CURVES[2][4], 29, 18, 2)
-    emit_unsat(out, "BLS12_381U", "BLS12_381", CURVES[3][1], CURVES[3][3], CURVES[3][4], 28, 14, 1)
+               solinas=((128, -1), (96, -1), (32, 1)), sparse=True, extra=bb(1))
+    emit_unsat(out, "P521U", "P521", CURVES[2][1], CURVES[2][3], CURVES[2][4], 29, 18, 2, extra=bb(2))
+    emit_unsat(out, "BLS12_381U", "BLS12_381", CURVES[3][1], CURVES[3][3], CURVES[3][4], 28, 14, 1, extra=bb(3))
     L = 8
     out.append("struct ED25519;")
     emit_unsat(out, "ED25519U", "ED25519", P25519, ED_GX, ED_GY, 29, 9, 3, extra=(("D2", 2 * ED_D % P25519),))

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Differential soak on the GPU: the default kernels (unsaturated limbs, windowed ladders, wide
-combs, fused double-scalar) against the reference-mirroring kernels (saturated canonical limbs,
-complete formulas, 4-bit windows) on random batches of random sizes, all curves.
+"""Differential soak on the GPU: the default kernels (Jacobian / extended coordinates, signed
+windows, wide combs, fused double-scalar) against the reference-mirroring kernels (complete
+formulas in homogeneous coordinates, 4-bit windows, 4-bit comb and group law on saturated
+canonical limbs) on random batches of random sizes, all curves.
 
     python tools/soak.py [seconds] [seed]
 
