@@ -104,14 +104,14 @@ WORKLOADS = {
 # read from inside this process, so the figure is the committed measurement of this very
 # workload, not a live one; null where no profile has been taken.
 MEASURED_TRAFFIC = {
-    "p256r1_var_2^20": {"bytes": 2 * (6800172443 + 93819216) + 3654147990 + 70297040,
-                        "fetch_raw": 6800172443 + 93819216, "write": 3654147990 + 70297040,
+    "p256r1_var_2^20": {"bytes": 2 * (6785633645 + 93791160) + 3669083030 + 70265624,
+                        "fetch_raw": 6785633645 + 93791160, "write": 3669083030 + 70265624,
                         "source": "profiles/r01_p256r1_var_u29.json"},
-    "ed25519_base_2^20": {"bytes": 2 * (1114466784 + 95245696) + 101870378 + 103888809,
-                          "fetch_raw": 1114466784 + 95245696, "write": 101870378 + 103888809,
+    "ed25519_base_2^20": {"bytes": 2 * (1115831200 + 95152722) + 101867882 + 103896768,
+                          "fetch_raw": 1115831200 + 95152722, "write": 101867882 + 103896768,
                           "source": "profiles/r01_ed25519_base.json"},
-    "x25519_2^20": {"bytes": 2 * (31276132 + 92950162) + 101712091 + 70254592,
-                    "fetch_raw": 31276132 + 92950162, "write": 101712091 + 70254592,
+    "x25519_2^20": {"bytes": 2 * (31359716 + 92948388) + 101712000 + 70254674,
+                    "fetch_raw": 31359716 + 92948388, "write": 101712000 + 70254674,
                     "source": "profiles/r01_x25519.json"},
 }
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
