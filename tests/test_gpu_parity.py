@@ -229,6 +229,26 @@ def test_default_and_mirror_kernels_agree_on_a_large_batch(engine, oracle, curve
     assert out[idx].cpu().numpy().tobytes() == want[0] and f[idx].cpu().numpy().tobytes() == want[1]
 
 
+@pytest.mark.parametrize("curve", ALL)
+def test_reference_layout_comb_variants(engine, oracle, curve):
+    """ECCX_TABLE_IN_L2 / ECCX_TABLE_IN_LDS select the reference's 4-bit comb (table read through
+    L1/L2, or -- edwards25519 -- staged in LDS, BASELINE.json configs[2]) instead of the default
+    16-bit-window path: same bytes and flags, also for a batch large enough to engage the
+    1024-thread LDS workgroups on every CU."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    for n in (300, 1 << 17):
+        ks = torch.from_numpy(W.random_scalars(curve, n, seed=601 + n)).to(dev)
+        ref_out, ref_fl = engine.scalarmul_base_t(curve, ks)
+        for lds in (False, True):
+            out, fl = engine.scalarmul_base_t(curve, ks, table_in_lds=lds)
+            assert torch.equal(out, ref_out) and torch.equal(fl, ref_fl), (curve, n, lds)
+        idx = torch.arange(0, n, max(1, n // 64), device=dev)
+        want = oracle.base(curve, ks[idx].cpu().numpy().tobytes(), threads=4)
+        assert ref_out[idx].cpu().numpy().tobytes() == want[0] and ref_fl[idx].cpu().numpy().tobytes() == want[1]
+
+
 # ---- the reference's own known-answer vectors, on the GPU ---------------------------------
 @pytest.mark.parametrize("curve", ["p256r1", "p384r1", "p521r1"])
 def test_nist_kg_on_gpu(engine, oracle, curve):
