@@ -249,6 +249,22 @@ def test_reference_layout_comb_variants(engine, oracle, curve):
         assert ref_out[idx].cpu().numpy().tobytes() == want[0] and ref_fl[idx].cpu().numpy().tobytes() == want[1]
 
 
+@pytest.mark.parametrize("curve", ["p256r1", "ed25519"])
+def test_host_buffer_path_in_chunks(engine, curve):
+    """eccx_scalarmul_var on host buffers sends batches of 2^17 units and more through in four
+    chunks whose PCIe copies overlap the neighbouring chunk's kernels; a ragged size must give
+    exactly what the device-resident path gives for the same inputs."""
+    import torch
+
+    n = (1 << 17) + 777
+    ks = W.random_scalars(curve, n, seed=701)
+    d_k = torch.from_numpy(ks).cuda()
+    pts, _ = engine.scalarmul_base_t(curve, torch.from_numpy(W.random_scalars(curve, n, seed=702)).cuda())
+    want_out, want_fl = engine.scalarmul_var_t(curve, d_k, pts)
+    got = engine.scalarmul_var(curve, ks.tobytes(), pts.cpu().numpy().tobytes())
+    assert got[0] == want_out.cpu().numpy().tobytes() and got[1] == want_fl.cpu().numpy().tobytes()
+
+
 # ---- the reference's own known-answer vectors, on the GPU ---------------------------------
 @pytest.mark.parametrize("curve", ["p256r1", "p384r1", "p521r1"])
 def test_nist_kg_on_gpu(engine, oracle, curve):
