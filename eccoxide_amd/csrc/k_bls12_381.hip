@@ -1,6 +1,5 @@
 // Kernel instantiations for BLS12_381 (see k_weierstrass.inc).
 #define ECCX_CURVE BLS12_381
 #define ECCX_CURVE_U BLS12_381U
-#define ECCX_ROWS_PLAIN true
 #define ECCX_OPS_NAME ops_BLS12_381
 #include "k_weierstrass.inc"

@@ -77,9 +77,7 @@ __global__ void __launch_bounds__(ED_LDS_BLOCK) k_ed_scalarmul_base_lds(size_t n
 //   MODE 3: curve25519 x-only: u = X/Z with 0 for Z = 0, 32 little-endian bytes per unit,
 //           flag 1 = result is zero (curve25519.rs:529-532; x25519.rs:33-35)
 enum { NORM_HOMOGENEOUS = 0, NORM_JACOBIAN = 1, NORM_EDWARDS = 2, NORM_MONTGOMERY_U = 3 };
-// PLAIN: the rows hold plain canonical integers (written by the unsaturated kernels) and are
-// taken into this kernel's Montgomery domain on load.
-template <class C, int MODE, int U, bool PLAIN = false>
+template <class C, int MODE, int U>
 __global__ void __launch_bounds__(WG) k_batch_to_affine(size_t n, const uint32_t* __restrict__ pts,
                                                         uint8_t* __restrict__ out, uint8_t* __restrict__ flags) {
   constexpr int L = C::L;
@@ -98,7 +96,6 @@ __global__ void __launch_bounds__(WG) k_batch_to_affine(size_t n, const uint32_t
         const uint32_t* r = pts + i * (size_t)W3 + 2 * L;
 #pragma unroll
         for (int j = 0; j < L; ++j) z.v[j] = r[j];
-        if constexpr (PLAIN) fe_to_mont<C>(z, z);
         if (fe_is_zero<C>(z)) z = one;  // z_inverse_ct substitutes 1 (projective.rs:655-659)
       }
       if (u == 0) pre[0] = z;
@@ -115,7 +112,6 @@ __global__ void __launch_bounds__(WG) k_batch_to_affine(size_t n, const uint32_t
         const uint32_t* r = pts + i * (size_t)W3;
 #pragma unroll
         for (int j = 0; j < L; ++j) { x.v[j] = r[j]; y.v[j] = r[L + j]; z.v[j] = r[2 * L + j]; }
-        if constexpr (PLAIN) { fe_to_mont<C>(x, x); fe_to_mont<C>(y, y); fe_to_mont<C>(z, z); }
         present = !fe_is_zero<C>(z);
         if (!present) z = one;
       }

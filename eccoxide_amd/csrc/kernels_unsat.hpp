@@ -17,7 +17,7 @@
 // wave-uniform control flow.  Only the field layer carries bounds: 28/29-bit limbs,
 // single-instruction MACs, real squarings, carry-free additions, bounds tracked in the types
 // (U<C, K, V>, see ufe.hpp), so an unsafe composition does not compile.  Results leave as
-// canonical plain integers (rows X, Y, Z) for k_batch_to_affine.
+// canonical limbs of the saturated field (rows X, Y, Z) for k_batch_to_affine.
 #pragma once
 #include "kernels_fast.hpp"
 #include "ufe.hpp"
@@ -364,10 +364,10 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_var_uns
     }
     if constexpr (FUSED) ucomb_accumulate<CU>(q, base_scalars + idx * (size_t)SB, utable);
     if (active) {
-      Pt<CS> res;  // canonical plain integers
-      u_to_canonical<CU>(res.x, q.x);
-      u_to_canonical<CU>(res.y, q.y);
-      u_to_canonical<CU>(res.z, q.z);
+      Pt<CS> res;  // the saturated field's canonical limbs, as k_batch_to_affine takes them
+      u_to_sat_mont<CU>(res.x, q.x);
+      u_to_sat_mont<CU>(res.y, q.y);
+      u_to_sat_mont<CU>(res.z, q.z);
       row_store<CS>(rows_out + idx * (size_t)W3, res);
       flags[idx] = rejected ? 2 : 0;
     }
@@ -498,10 +498,10 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_base_un
     u_set_zero(q.z);  // infinity
     ucomb_accumulate<CU>(q, k, table);
     if (active) {
-      Pt<CS> res;  // canonical plain integers
-      u_to_canonical<CU>(res.x, q.x);
-      u_to_canonical<CU>(res.y, q.y);
-      u_to_canonical<CU>(res.z, q.z);
+      Pt<CS> res;  // the saturated field's canonical limbs, as k_batch_to_affine takes them
+      u_to_sat_mont<CU>(res.x, q.x);
+      u_to_sat_mont<CU>(res.y, q.y);
+      u_to_sat_mont<CU>(res.z, q.z);
       row_store<CS>(rows_out + idx * (size_t)W3, res);
       flags[idx] = 0;
     }
@@ -1127,10 +1127,9 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_var_mir
     if (active) {
       // the saturated tail expects canonical Montgomery limbs
       Pt<CS> res;
-      Fe<L> c;
-      u_to_canonical<CU>(c, q.x); fe_to_mont<CS>(res.x, c);
-      u_to_canonical<CU>(c, q.y); fe_to_mont<CS>(res.y, c);
-      u_to_canonical<CU>(c, q.z); fe_to_mont<CS>(res.z, c);
+      u_to_sat_mont<CU>(res.x, q.x);
+      u_to_sat_mont<CU>(res.y, q.y);
+      u_to_sat_mont<CU>(res.z, q.z);
       store_result<CS>(idx, res, rejected, out, flags, proj, opts);
     }
   }

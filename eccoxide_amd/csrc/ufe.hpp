@@ -618,4 +618,22 @@ ECCX_DEV void u_to_canonical(Fe<C::Sat::L>& out, const U<C, K, V>& a) {
   cond_sub_p<typename C::Sat>(out, t, 0u);  // p -> 0
 }
 
+// working form -> the SATURATED twin's working form (canonical Montgomery limbs for the Montgomery
+// fields, canonical plain integers otherwise): what fe.hpp code (normalisation, result tails) takes
+template <class C, int K, int V>
+ECCX_DEV void u_to_sat_mont(Fe<C::Sat::L>& out, const U<C, K, V>& a) {
+  if constexpr (UB<C>::MONT) {
+    // (a * R_sat + m p) / R with a < 3p, R_sat < p: below p (1 + 3p/R), one conditional subtraction
+    auto r = u_mul_k<C>(u_reduce(a), C::RS);
+    Fe<C::Sat::L> s;
+    u_to_sat<C>(s, r);
+    uint32_t t[C::Sat::L];
+#pragma unroll
+    for (int i = 0; i < C::Sat::L; ++i) t[i] = s.v[i];
+    cond_sub_p<typename C::Sat>(out, t, 0u);
+  } else {
+    u_to_canonical<C>(out, a);
+  }
+}
+
 }  // namespace eccx

@@ -123,6 +123,10 @@ def emit_unsat(out, name, sat_name, p, gx, gy, bits, n, kind, extra=(), solinas=
     out.append(arr("ONE", digits(R % p, bits, n)))
     out.append(arr("R2", digits(R * R % p, bits, n)))
     out.append(arr("BIAS", bias))
+    # R of the saturated twin (2^(32 L) mod p, plain digits): multiplying by it on the way out
+    # yields the twin's Montgomery form directly
+    Ls = (pbits + 31) // 32
+    out.append(arr("RS", digits(((1 << (32 * Ls)) % p) if mont else 1, bits, n)))
     # Solinas form p + 1 = 2^PBITS + sum(sign * 2^e): lets the weak reduction take off q*p with
     # shifts of q instead of multiplications (kind 0 only); terms as (limb, shift, sign)
     if solinas:
