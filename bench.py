@@ -135,7 +135,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1 << 17)
     ap.add_argument("--variant", default="default", choices=["default", "mirror", "lds", "l2"],
                     help="default: fast kernels; mirror: reference-mirroring kernels; "
-                         "lds / l2: ed25519 fixed base with the comb table forced into LDS / read through L2")
+                         "lds: ed25519 fixed base with a signed 6-bit comb table resident in LDS; "
+                         "l2: the reference's 4-bit comb read through L2")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

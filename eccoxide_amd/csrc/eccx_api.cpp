@@ -48,6 +48,7 @@ struct eccx_ctx {
   hipStream_t in_stream = nullptr, out_stream = nullptr;  // host-buffer entry points: copies beside the compute
   uint32_t* comb[NCURVES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   uint32_t* comb_u[NCURVES] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // unsaturated-field copies
+  uint32_t* comb_lds[NCURVES] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // images for the LDS variant
   std::mutex comb_mu;
   uint32_t* scratch = nullptr;
   size_t scratch_words = 0;
@@ -235,6 +236,43 @@ int ensure_comb(eccx_ctx* ctx, int curve, const CurveOps* ops) {
   return ECCX_OK;
 }
 
+// table image of the LDS-resident fixed-base variant: entry (w, d) = d * 2^(bits*w) * G for the
+// digits 0 .. 2^(bits-1), built like the wide tables by the engine's own variable-base path
+int ensure_comb_lds(eccx_ctx* ctx, int curve, const CurveOps* ops) {
+  std::lock_guard<std::mutex> g(ctx->comb_mu);
+  if (ctx->comb_lds[curve]) return ECCX_OK;
+  const int sbytes = ops->info.sb;
+  const size_t entries = (size_t)ops->lds_windows * ops->lds_digits, pb = 2 * (size_t)ops->info.fb;
+  std::vector<uint8_t> k(entries * sbytes, 0);
+  for (int w = 0; w < ops->lds_windows; ++w)
+    for (int d = 0; d < ops->lds_digits; ++d) {
+      uint8_t* row = k.data() + ((size_t)w * ops->lds_digits + d) * sbytes;
+      bool fits = true;
+      for (int bit = 0; bit < 16; ++bit)
+        if ((d >> bit) & 1) {
+          const int pos = w * ops->lds_bits + bit;
+          if (pos >= 8 * sbytes) { fits = false; break; }
+          row[sbytes - 1 - (pos >> 3)] |= (uint8_t)(1u << (pos & 7));
+        }
+      if (!fits) std::fill(row, row + sbytes, (uint8_t)0);
+    }
+  DevMem mem;
+  uint8_t *d_k = nullptr, *d_aff = nullptr, *d_fl = nullptr;
+  uint32_t* d_tab = nullptr;
+  HIP_TRY(ctx, mem.alloc(&d_k, k.size()));
+  HIP_TRY(ctx, mem.alloc(&d_aff, entries * pb));
+  HIP_TRY(ctx, mem.alloc(&d_fl, entries));
+  HIP_TRY(ctx, mem.alloc(&d_tab, entries * (size_t)ops->lds_entry_words * sizeof(uint32_t)));
+  HIP_TRY(ctx, hipMemcpyAsync(d_k, k.data(), k.size(), hipMemcpyHostToDevice, ctx->stream));
+  int rc = launch_var(ctx, ops, entries, d_k, nullptr, d_aff, d_fl, nullptr, K_BASE_IS_GENERATOR, false, ctx->stream);
+  if (rc) return rc;
+  HIP_TRY(ctx, ops->lds_convert(ctx->stream, entries, d_aff, d_tab));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  mem.release(d_tab);
+  ctx->comb_lds[curve] = d_tab;
+  return ECCX_OK;
+}
+
 uint32_t kopts_of(uint32_t opts) { return (opts & ECCX_VALIDATE_POINTS) ? K_VALIDATE : 0u; }
 
 size_t proj_bytes(const CurveOps* ops) { return (size_t)(ops->info.edwards ? 4 : 3) * ops->info.fb; }
@@ -415,6 +453,8 @@ void eccx_shutdown(eccx_ctx* ctx) {
     if (t) (void)hipFree(t);
   for (auto& t : ctx->comb_u)
     if (t) (void)hipFree(t);
+  for (auto& t : ctx->comb_lds)
+    if (t) (void)hipFree(t);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->jac) (void)hipFree(ctx->jac);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -477,13 +517,14 @@ int eccx_scalarmul_base_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_sc
                                     static_cast<uint8_t*>(d_flags)));
     return ECCX_OK;
   }
-  // LDS-staged table: forced by ECCX_TABLE_IN_LDS, excluded by ECCX_TABLE_IN_L2, otherwise used
-  // for batches large enough to amortise staging 96 KiB per workgroup
-  const bool lds = (opts & ECCX_TABLE_IN_LDS) || (!(opts & ECCX_TABLE_IN_L2) && n >= ((size_t)1 << 16));
-  if (!d_proj && lds && ops->base_lds && ops->to_affine_hom) {
+  // LDS-resident table (ECCX_TABLE_IN_LDS, edwards25519): signed 6-bit windows, the widest table
+  // that fits 160 KiB
+  if (!d_proj && (opts & ECCX_TABLE_IN_LDS) && ops->base_lds && ops->lds_convert && ops->to_affine_hom) {
+    rc = ensure_comb_lds(ctx, curve, ops);
+    if (rc) return rc;
     rc = ensure_rows(ctx, ops, n);
     if (rc) return rc;
-    HIP_TRY(ctx, ops->base_lds(ctx->cus, s, n, static_cast<const uint8_t*>(d_scalars), ctx->comb[curve], ctx->jac,
+    HIP_TRY(ctx, ops->base_lds(ctx->cus, s, n, static_cast<const uint8_t*>(d_scalars), ctx->comb_lds[curve], ctx->jac,
                                static_cast<uint8_t*>(d_flags)));
     HIP_TRY(ctx, ops->to_affine_hom(norm_grid(ctx, n), s, n, ctx->jac, static_cast<uint8_t*>(d_out),
                                     static_cast<uint8_t*>(d_flags)));

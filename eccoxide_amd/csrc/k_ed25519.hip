@@ -16,14 +16,18 @@ hipError_t base_(int grid, hipStream_t s, size_t n, const uint8_t* scalars, cons
 }
 hipError_t base_lds_(int cus, hipStream_t s, size_t n, const uint8_t* scalars, const uint32_t* table, uint32_t* rows,
                      uint8_t* flags) {
-  constexpr size_t lds_bytes = (size_t)64 * 16 * 3 * ED25519::L * sizeof(uint32_t);  // 96 KiB
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ed_scalarmul_base_lds<ED25519>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ed_scalarmul_base_lds6<ED25519U>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)ED_LDS_BYTES);
   if (attr != hipSuccess) return attr;
   size_t need = (n + ED_LDS_BLOCK - 1) / ED_LDS_BLOCK;
   int grid = (int)(need < (size_t)cus ? (need ? need : 1) : (size_t)cus);  // one workgroup per CU
-  hipLaunchKernelGGL(k_ed_scalarmul_base_lds<ED25519>, dim3(grid), dim3(ED_LDS_BLOCK), lds_bytes, s, n, scalars, table,
+  hipLaunchKernelGGL(k_ed_scalarmul_base_lds6<ED25519U>, dim3(grid), dim3(ED_LDS_BLOCK), ED_LDS_BYTES, s, n, scalars, table,
                      rows, flags);
+  return hipGetLastError();
+}
+hipError_t lds_convert_(hipStream_t s, size_t entries, const uint8_t* affine, uint32_t* table) {
+  hipLaunchKernelGGL(k_ed_affine_to_niels_unsat<ED25519U>, dim3((unsigned)((entries + 127) / 128)), dim3(128), 0, s, entries, affine,
+                     table, ED_LDS_ENTRY_WORDS);
   return hipGetLastError();
 }
 hipError_t to_affine_hom_(int grid, hipStream_t s, size_t n, const uint32_t* rows, uint8_t* out, uint8_t* flags) {
@@ -31,7 +35,7 @@ hipError_t to_affine_hom_(int grid, hipStream_t s, size_t n, const uint32_t* row
   return hipGetLastError();
 }
 hipError_t comb_convert_(hipStream_t s, size_t entries, const uint8_t* affine, uint32_t* table) {
-  hipLaunchKernelGGL(k_ed_affine_to_niels_unsat<ED25519U>, dim3((unsigned)((entries + 127) / 128)), dim3(128), 0, s, entries, affine, table);
+  hipLaunchKernelGGL(k_ed_affine_to_niels_unsat<ED25519U>, dim3((unsigned)((entries + 127) / 128)), dim3(128), 0, s, entries, affine, table, ED_U_ENTRY_WORDS);
   return hipGetLastError();
 }
 hipError_t base_w8_(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint32_t* table, uint32_t* rows,
@@ -76,7 +80,7 @@ hipError_t launch_x25519_to_u(int grid, hipStream_t s, size_t n, const uint32_t*
   return hipGetLastError();
 }
 const CurveOps& ops_ED25519() {
-  static const CurveOps o = {{ED25519::FB, ED25519::SB, ED25519::L, 4 * ED25519::L, 0, 1, ED_VAR_ROW_WORDS, row_words<ED25519::L>()}, var_, base_, var_fast_, base_lds_, to_affine_hom_, var_grid_, var_fast_grid_, to_affine_hom_, point_add_, ED_U_ENTRY_WORDS, comb_bits<ED25519U>(), comb_convert_, base_w8_, var_fused_};
+  static const CurveOps o = {{ED25519::FB, ED25519::SB, ED25519::L, 4 * ED25519::L, 0, 1, ED_VAR_ROW_WORDS, row_words<ED25519::L>()}, var_, base_, var_fast_, base_lds_, to_affine_hom_, var_grid_, var_fast_grid_, to_affine_hom_, point_add_, ED_U_ENTRY_WORDS, comb_bits<ED25519U>(), comb_convert_, base_w8_, ED_LDS_BITS, ED_LDS_WINDOWS, ED_LDS_DIGITS, ED_LDS_ENTRY_WORDS, lds_convert_, var_fused_};
   return o;
 }
 }  // namespace eccx

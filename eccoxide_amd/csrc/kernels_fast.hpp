@@ -2,7 +2,6 @@
 //   k_batch_to_affine<C>     Point::to_affine (projective.rs:655-682) for a whole batch: each
 //       lane normalises U units with ONE field inversion (Montgomery's trick), so the
 //       ~380-multiplication Fermat inversion is paid once per 8 or 16 units instead of per unit.
-//   k_ed_scalarmul_base_lds  the reference-layout Ed25519 comb with the table staged in LDS.
 // The ladders themselves are in kernels_unsat.hpp (default) and kernels.hpp (reference-mirroring).
 #pragma once
 #include "inv_gcd.hpp"
@@ -11,61 +10,6 @@
 namespace eccx {
 
 constexpr int FAST_TABLE_ROWS = 17;  // rows of the per-lane window table (entries 0..16 of the signed 5-bit windows)
-
-// edwards25519 fixed base with the whole comb table staged in LDS (BASELINE.json configs[2]:
-// "comb table in LDS").  One 1024-thread workgroup per CU shares a 96 KiB image of the table
-// (64 windows x 16 digits x {x, y, 2d*x*y}, digit 0 = the neutral element so the loop has no
-// branch); lanes read their entry with ds_read_b128.  Same arithmetic as the default path of
-// k_ed_scalarmul_base (7-multiplication cached addition), which reads the table through L1/L2.
-constexpr int ED_LDS_BLOCK = 1024;
-template <class C>
-__global__ void __launch_bounds__(ED_LDS_BLOCK) k_ed_scalarmul_base_lds(size_t n, const uint8_t* __restrict__ scalars,
-                                                                        const uint32_t* __restrict__ table,
-                                                                        uint32_t* __restrict__ rows_out,
-                                                                        uint8_t* __restrict__ flags) {
-  constexpr int L = C::L;
-  constexpr int EW = 3 * L;  // LDS words per entry
-  extern __shared__ uint4 lds4[];
-  uint32_t* lds = reinterpret_cast<uint32_t*>(lds4);
-  for (int i = threadIdx.x; i < 64 * 16 * EW; i += ED_LDS_BLOCK) {
-    const int e = i / EW, j = i - e * EW;
-    uint32_t v;
-    if ((e & 15) == 0) v = (j >= L && j < 2 * L) ? C::ONE[0] * (j == L) : 0u;  // (0, 1, 0)
-    else v = table[(size_t)e * (4 * L) + (j < 2 * L ? j : j + L)];              // x, y | skip t | 2dxy
-    lds[i] = v;
-  }
-  __syncthreads();
-  constexpr int W3 = row_words<L>();
-  for (size_t base = (size_t)blockIdx.x * ED_LDS_BLOCK; base < n; base += (size_t)gridDim.x * ED_LDS_BLOCK) {
-    const size_t gid = base + threadIdx.x;
-    const bool active = gid < n;
-    const size_t idx = active ? gid : n - 1;
-    const uint8_t* __restrict__ k = scalars + idx * 32;
-    EdPt<C> q;
-    ed_set_identity<C>(q);
-    for (int w = 0; w < 64; ++w) {
-      uint32_t byte = k[31 - (w >> 1)];
-      uint32_t d = (w & 1) ? (byte >> 4) : (byte & 0x0f);
-      const uint4* e = reinterpret_cast<const uint4*>(lds + (w * 16 + d) * EW);
-      uint32_t v[EW];
-#pragma unroll
-      for (int i = 0; i < EW / 4; ++i) {
-        uint4 t = e[i];
-        v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
-      }
-      Fe<L> x2, y2, t2d;
-#pragma unroll
-      for (int i = 0; i < L; ++i) { x2.v[i] = v[i]; y2.v[i] = v[L + i]; t2d.v[i] = v[2 * L + i]; }
-      ed_add_cached<C>(q, q, x2, y2, t2d);
-    }
-    if (active) {
-      Pt<C> row;
-      row.x = q.x; row.y = q.y; row.z = q.z;
-      row_store<C>(rows_out + idx * (size_t)W3, row);
-      flags[idx] = 0;
-    }
-  }
-}
 
 // Normalise a batch of un-normalised points (rows of W3 words: X, Y, Z Montgomery limbs).
 //   MODE 0: homogeneous x = X/Z, y = Y/Z, big-endian bytes (projective.rs:655-682)

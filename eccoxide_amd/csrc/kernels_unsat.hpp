@@ -612,9 +612,9 @@ constexpr int ED_U_ENTRY_WORDS = ((27 + ECCX_ENTRY_ALIGN - 1) / ECCX_ENTRY_ALIGN
 
 // (x, y, z, t) += the table point given as (y2 - x2, y2 + x2, 2d*x2*y2), Z2 = 1: Point::add with
 // the operand prepared in the table (curve25519.rs:695-729), 7 products
-template <class CU>
+template <class CU, int KT = 1, int VT = 3>
 ECCX_DEV void ued_add_niels(U<CU, 1, 3>& qx, U<CU, 1, 3>& qy, U<CU, 1, 3>& qz, U<CU, 1, 3>& qt, const U<CU, 1, 3>& ym,
-                            const U<CU, 1, 3>& yp, const U<CU, 1, 3>& t2d) {
+                            const U<CU, 1, 3>& yp, const U<CU, KT, VT>& t2d) {
   auto aa = u_mul(u_sub(qy, qx), ym);
   auto bb = u_mul(u_add(qy, qx), yp);
   auto cc = u_mul(qt, t2d);
@@ -652,7 +652,8 @@ ECCX_DEV void ued_comb_accumulate(U<CU, 1, 3>& qx, U<CU, 1, 3>& qy, U<CU, 1, 3>&
   }
 }
 template <class CU>
-__global__ void k_ed_affine_to_niels_unsat(size_t entries, const uint8_t* __restrict__ affine, uint32_t* __restrict__ table) {
+__global__ void k_ed_affine_to_niels_unsat(size_t entries, const uint8_t* __restrict__ affine, uint32_t* __restrict__ table,
+                                           int stride_words) {
   using CS = typename CU::Sat;
   constexpr int L = CS::L;
   constexpr int N = CU::N;
@@ -670,9 +671,8 @@ __global__ void k_ed_affine_to_niels_unsat(size_t entries, const uint8_t* __rest
   const auto ym = u_reduce(u_sub(y, x));
   const auto yp = u_reduce(u_add(y, x));
   const auto t2d = u_reduce(u_mul(u_mul(x, y), d2));
-  uint32_t* o = table + i * ED_U_ENTRY_WORDS;
-#pragma unroll
-  for (int k = 0; k < ED_U_ENTRY_WORDS; ++k)
+  uint32_t* o = table + i * (size_t)stride_words;
+  for (int k = 0; k < stride_words; ++k)
     o[k] = k < N ? ym.v[k] : (k < 2 * N ? yp.v[k - N] : (k < 3 * N ? t2d.v[k - 2 * N] : 0u));
 }
 
@@ -1131,6 +1131,84 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_var_mir
       u_to_sat_mont<CU>(res.y, q.y);
       u_to_sat_mont<CU>(res.z, q.z);
       store_result<CS>(idx, res, rejected, out, flags, proj, opts);
+    }
+  }
+}
+
+// ---- edwards25519 fixed base with the comb table in LDS (BASELINE.json configs[2]) -------------
+// The widest table the 160 KiB of LDS can hold: signed 6-bit windows, 43 windows x 33 entries
+// (digit 0 = the neutral element, digits 1..32; a negative digit swaps y - x with y + x and negates
+// 2d*x*y) x 28 words = 155.2 KiB, one 1024-thread workgroup per CU, lanes read their entry with
+// ds_read_b128.  43 seven-product additions per unit against 16 for the default path, whose
+// 134 MB table cannot live in LDS: this variant exists to measure exactly that trade
+// (ECCX_TABLE_IN_LDS).
+constexpr int ED_LDS_BLOCK = 1024;
+constexpr int ED_LDS_BITS = 6;
+constexpr int ED_LDS_WINDOWS = (256 + 1 + ED_LDS_BITS - 1) / ED_LDS_BITS;   // 43
+constexpr int ED_LDS_DIGITS = (1 << (ED_LDS_BITS - 1)) + 1;                  // 0..32
+constexpr int ED_LDS_ENTRY_WORDS = 28;
+constexpr size_t ED_LDS_BYTES = (size_t)ED_LDS_WINDOWS * ED_LDS_DIGITS * ED_LDS_ENTRY_WORDS * sizeof(uint32_t);
+static_assert(ED_LDS_BYTES <= 160 * 1024, "the table must fit the LDS of one CU");
+
+template <class CU>
+__global__ void __launch_bounds__(ED_LDS_BLOCK) k_ed_scalarmul_base_lds6(size_t n, const uint8_t* __restrict__ scalars,
+                                                                         const uint32_t* __restrict__ table,
+                                                                         uint32_t* __restrict__ rows_out,
+                                                                         uint8_t* __restrict__ flags) {
+  using CS = typename CU::Sat;
+  constexpr int L = CS::L;
+  constexpr int N = CU::N;
+  constexpr int EW = ED_LDS_ENTRY_WORDS;
+  static_assert(3 * N <= EW, "entry layout");
+  using T = U<CU, 1, 3>;
+  extern __shared__ uint4 lds4[];
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(table);
+    for (int i = threadIdx.x; i < ED_LDS_WINDOWS * ED_LDS_DIGITS * EW / 4; i += ED_LDS_BLOCK) lds4[i] = src[i];
+  }
+  __syncthreads();
+  for (size_t base = (size_t)blockIdx.x * ED_LDS_BLOCK; base < n; base += (size_t)gridDim.x * ED_LDS_BLOCK) {
+    const size_t gid = base + threadIdx.x;
+    const bool active = gid < n;
+    const size_t idx = active ? gid : n - 1;
+    const uint8_t* __restrict__ k = scalars + idx * 32;
+    T qx, qy, qz, qt;  // the neutral element (0, 1, 1, 0)
+    u_set_zero(qx); u_set_zero(qy); u_set_zero(qz); u_set_zero(qt);
+    qy.v[0] = 1; qz.v[0] = 1;
+    for (int w = 0; w < ED_LDS_WINDOWS; ++w) {
+      // signed (Booth) digit of window w of the big-endian scalar: bits 6w-1 .. 6w+5
+      const int pos = ED_LDS_BITS * w - 1 + 8;
+      const int bi = pos >> 3;
+      const uint32_t b0 = (bi >= 1 && bi <= 32) ? k[32 - bi] : 0u;
+      const uint32_t b1 = (bi + 1 <= 32) ? k[32 - bi - 1] : 0u;
+      const uint32_t w7 = ((b0 | (b1 << 8)) >> (pos & 7)) & 0x7fu;
+      const uint32_t sgn = ~((w7 >> ED_LDS_BITS) - 1u);
+      const uint32_t m = (((1u << (ED_LDS_BITS + 1)) - w7 - 1u) & sgn) | (w7 & ~sgn);
+      const uint32_t d = (m >> 1) + (m & 1u);
+      const bool neg = (sgn & 1u) != 0;
+      const uint4* e = lds4 + (size_t)(w * ED_LDS_DIGITS + d) * (EW / 4);
+      uint32_t ew[EW];
+#pragma unroll
+      for (int i = 0; i < EW / 4; ++i) {
+        const uint4 v = e[i];
+        ew[4 * i] = v.x; ew[4 * i + 1] = v.y; ew[4 * i + 2] = v.z; ew[4 * i + 3] = v.w;
+      }
+      T a, b, t2d, ym, yp;
+#pragma unroll
+      for (int i = 0; i < N; ++i) { a.v[i] = ew[i]; b.v[i] = ew[N + i]; t2d.v[i] = ew[2 * N + i]; }
+      u_select(ym, neg, b, a);
+      u_select(yp, neg, a, b);
+      U<CU, 2, 4> t2;
+      u_select(t2, neg, u_neg(t2d), u_as<2, 4>(t2d));
+      ued_add_niels<CU, 2, 4>(qx, qy, qz, qt, ym, yp, t2);
+    }
+    if (active) {
+      Pt<CS> row;
+      u_to_canonical<CU>(row.x, qx);
+      u_to_canonical<CU>(row.y, qy);
+      u_to_canonical<CU>(row.z, qz);
+      row_store<CS>(rows_out + idx * (size_t)row_words<L>(), row);
+      flags[idx] = 0;
     }
   }
 }

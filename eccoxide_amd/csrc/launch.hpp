@@ -60,6 +60,11 @@ struct CurveOps {
                            uint32_t* rows, uint8_t* flags);
   // fused double-scalar u1*G + u2*Q (may be null): var_fast's ladder on (u2, q) followed by the
   // comb of u1 over utable, rows for to_affine_var; same grid and scratch as var_fast
+  // table of the LDS-resident fixed-base variant (base_lds; may be 0 / null): lds_windows x lds_digits
+  // entries of lds_entry_words, entry (w, d) = d * 2^(lds_bits * w) * G, made by lds_convert from
+  // affine bytes
+  int lds_bits, lds_windows, lds_digits, lds_entry_words;
+  hipError_t (*lds_convert)(hipStream_t s, size_t entries, const uint8_t* affine, uint32_t* table);
   hipError_t (*var_fused)(int grid, hipStream_t s, size_t n, const uint8_t* u2, const uint8_t* q, uint32_t* rows,
                           uint8_t* flags, uint32_t* scratch, uint32_t opts, const uint8_t* u1, const uint32_t* utable);
 };

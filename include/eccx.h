@@ -78,12 +78,12 @@ enum {
                                      ECCX_VALIDATE_POINTS) give unspecified output by default and
                                      the reference's arithmetic under this option. */
   ,
-  ECCX_TABLE_IN_LDS = 1u << 2,   /* fixed base, edwards25519 only: use the reference's 4-bit comb
-                                     (64 additions) with the whole table (96 KiB) staged in LDS,
-                                     one 1024-thread workgroup per CU.  The default fixed-base
-                                     path uses 16-bit windows (16 additions) over a 117 MB table
-                                     the engine builds for itself: same results, about 4x
-                                     faster; see DESIGN.md for the numbers. */
+  ECCX_TABLE_IN_LDS = 1u << 2,   /* fixed base, edwards25519 only: keep the comb table in LDS --
+                                     signed 6-bit windows, the widest table 160 KiB can hold (43
+                                     additions), one 1024-thread workgroup per CU.  The default
+                                     fixed-base path uses 16-bit windows (16 additions) over a
+                                     134 MB table in HBM: same results, about 2x faster; see
+                                     DESIGN.md for the numbers. */
   ECCX_TABLE_IN_L2 = 1u << 3,    /* fixed base: the reference's 4-bit comb, table read through L1/L2 */
   ECCX_X25519_RAW_LADDER = 1u << 4, /* eccx_x25519: raw MontgomeryPoint::scale_bytes semantics */
   ECCX_SUBTRACT = 1u << 5          /* eccx_point_add: compute a - b */
