@@ -1,8 +1,7 @@
-// Kernels shared by the default paths:
-//   k_batch_to_affine<C>     Point::to_affine (projective.rs:655-682) for a whole batch: each
-//       lane normalises U units with ONE field inversion (Montgomery's trick), so the
-//       ~380-multiplication Fermat inversion is paid once per 8 or 16 units instead of per unit.
-// The ladders themselves are in kernels_unsat.hpp (default) and kernels.hpp (reference-mirroring).
+// k_batch_to_affine<C>: Point::to_affine (projective.rs:655-682) for a whole batch.  Each lane
+// normalises U units with ONE field inversion (Montgomery's trick), and that inversion is by
+// division steps (inv_gcd.hpp).  The ladders and combs that feed it are in kernels_unsat.hpp
+// (default) and kernels.hpp (reference-mirroring).
 #pragma once
 #include "inv_gcd.hpp"
 #include "kernels.hpp"
