@@ -51,8 +51,7 @@ def _var_unsat(n, nz, sb, a0, inv, sat_pairs, mont=True, norm_u=8):
     P-384, all n for BLS12-381,
     none for the Mersenne prime whose wrapped half shares the columns), a square n(n+1)/2 +
     n*nz.  Doubling = 4 products + 4 squares (a = -3) or 2 + 5 (a = 0), addition = 11 + 3;
-    ceil((8*sb + 1)/5) signed windows; the normalisation kernel stays saturated (inv and norm_u
-    are kept for reference: the inversion is no longer a multiplication chain)."""
+    ceil((8*sb + 1)/5) signed windows (inv, sat_pairs and norm_u are kept for reference only)."""
     mul, sqr = n * n + n * nz, n * (n + 1) // 2 + n * nz
     nwin = (8 * sb + 1 + 4) // 5
     dbls, adds = 1 + (nwin - 1) * 5, 14 + nwin
@@ -60,9 +59,13 @@ def _var_unsat(n, nz, sb, a0, inv, sat_pairs, mont=True, norm_u=8):
     conv = 5 if mont else 0                      # 2 products into the working form, 3 out of it
     n_mul = dm * dbls + 11 * adds + 15 + conv    # + Z^3 per table entry
     n_sqr = ds * dbls + 3 * adds + 15            # + Z^2 per table entry
-    # saturated products of the normalisation per unit (prefix product, 1/Z share, Z^-2, Z^-3, x, y,
-    # conversions); the inversion itself is division steps, not multiplications
-    norm = 10   # (the ladder hands its rows over in the saturated field's own form)
+    # the normalisation kernel works on the same unsaturated limbs: per unit a prefix product, the
+    # 1/Z share, Z^-2, Z^-3, x and y (7 products + 1 square) and 2 conversions out; the inversion
+    # itself is division steps, not multiplications
+    n_mul += 9
+    n_sqr += 1
+    sat_pairs = 0
+    norm = 0
     return {"mad": n_mul * mul + n_sqr * sqr, "pair": norm * sat_pairs}
 
 
@@ -72,24 +75,22 @@ WORKLOADS = {
     # fixed base, default path: 16-bit windows, 16 additions of 7 products (Edwards, 81 + 9 mads each)
     # or of 8 products + 3 squares (P-256) on unsaturated limbs, then the saturated normalisation
     "ed25519_base_2^20": ("ed25519", "base", 1 << 20, 96,
-                          {"mad": 16 * 7 * (81 + 9), "pair": 8 * (8 * 8 + 8)}),
+                          {"mad": (16 * 7 + 8) * (81 + 9), "pair": 0}),
     "p256r1_base_2^20": ("p256r1", "base", 1 << 20, 96,
-                         {"mad": 16 * (8 * (81 + 36) + 3 * (45 + 36)) + 3 * (81 + 36),
-                          "pair": 10 * (8 * 8 + 8 * 3)}),
+                         {"mad": 16 * (8 * (81 + 36) + 3 * (45 + 36)) + 9 * (81 + 36) + (45 + 36), "pair": 0}),
     # unsaturated 9 x 29 ladder: per bit 5 products (81 + 9 mads), 4 squares (45 + 9), one small multiple (9 + 1)
     "p384r1_base_2^19": ("p384r1", "base", 1 << 19, 144,
-                         {"mad": 24 * (8 * 252 + 3 * 161) + 3 * 252, "pair": 10 * 264}),
+                         {"mad": 24 * (8 * 252 + 3 * 161) + 9 * 252 + 161, "pair": 0}),
     "p521r1_base_2^19": ("p521r1", "base", 1 << 19, 198,
-                         {"mad": 33 * (8 * 324 + 3 * 171), "pair": 10 * 289}),
+                         {"mad": 33 * (8 * 324 + 3 * 171) + 9 * 324 + 171, "pair": 0}),
     "bls12_381_g1_base_2^20": ("bls12_381_g1", "base", 1 << 20, 128,
-                               {"mad": 16 * (8 * 392 + 3 * 301) + 3 * 392, "pair": 10 * 288}),
+                               {"mad": 16 * (8 * 392 + 3 * 301) + 9 * 392 + 301, "pair": 0}),
     "x25519_2^20": ("ed25519", "x25519", 1 << 20, 96,
-                    {"mad": 256 * (5 * 90 + 4 * 54 + 10), "pair": 7 * (8 * 8 + 8)}),
+                    {"mad": 256 * (5 * 90 + 4 * 54 + 10) + 6 * 90, "pair": 0}),
     # edwards25519 variable base: 52 signed windows of 4 x (4 squares + 3 products) + (4 + 4) + a
     # 7-product addition; table of 16 cached multiples (1 doubling, 14 additions of 8, 16 x 2d*T)
     "ed25519_var_2^20": ("ed25519", "var", 1 << 20, 160,
-                         {"mad": (51 * 20 + 4) * 54 + (51 * 16 + 52 * 7 + 4 + 14 * 8 + 16 + 1) * 90,
-                          "pair": 8 * (8 * 8 + 8)}),
+                         {"mad": (51 * 20 + 4) * 54 + (51 * 16 + 52 * 7 + 4 + 14 * 8 + 16 + 1 + 8) * 90, "pair": 0}),
     # verify shape u1*G + u2*Q: the variable-base ladder + 16 mixed additions (8 products + 3 squares)
     "p256r1_verify_2^20": ("p256r1", "dsm", 1 << 20, 192,
                            {"mad": _var_unsat(9, 4, 32, 0, 383, 88, norm_u=16)["mad"] + 16 * (8 * 117 + 3 * 81),

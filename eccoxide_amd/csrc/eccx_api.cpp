@@ -519,14 +519,14 @@ int eccx_scalarmul_base_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_sc
   }
   // LDS-resident table (ECCX_TABLE_IN_LDS, edwards25519): signed 6-bit windows, the widest table
   // that fits 160 KiB
-  if (!d_proj && (opts & ECCX_TABLE_IN_LDS) && ops->base_lds && ops->lds_convert && ops->to_affine_hom) {
+  if (!d_proj && (opts & ECCX_TABLE_IN_LDS) && ops->base_lds && ops->lds_convert && ops->to_affine_var) {
     rc = ensure_comb_lds(ctx, curve, ops);
     if (rc) return rc;
     rc = ensure_rows(ctx, ops, n);
     if (rc) return rc;
     HIP_TRY(ctx, ops->base_lds(ctx->cus, s, n, static_cast<const uint8_t*>(d_scalars), ctx->comb_lds[curve], ctx->jac,
                                static_cast<uint8_t*>(d_flags)));
-    HIP_TRY(ctx, ops->to_affine_hom(norm_grid(ctx, n), s, n, ctx->jac, static_cast<uint8_t*>(d_out),
+    HIP_TRY(ctx, ops->to_affine_var(norm_grid(ctx, n), s, n, ctx->jac, static_cast<uint8_t*>(d_out),
                                     static_cast<uint8_t*>(d_flags)));
     return ECCX_OK;
   }

@@ -44,6 +44,36 @@ struct UEntry {
   U<CU, 1, 3> x, y, z, zz, zzz;
 };
 
+// un-normalised result rows handed to k_batch_to_affine_unsat: three field elements (X, Y, Z) as
+// tight digits, padded to 16 bytes
+template <class CU>
+constexpr int urow3_words() { return ((3 * CU::N + 3) / 4) * 4; }
+template <class CU>
+ECCX_DEV void u3_store(uint32_t* __restrict__ row, const U<CU, 1, 3>& x, const U<CU, 1, 3>& y, const U<CU, 1, 3>& z) {
+  constexpr int N = CU::N;
+  constexpr int W = urow3_words<CU>();
+  uint32_t w[W];
+#pragma unroll
+  for (int i = 0; i < W; ++i) w[i] = i < N ? x.v[i] : (i < 2 * N ? y.v[i - N] : (i < 3 * N ? z.v[i - 2 * N] : 0u));
+  uint4* dst = reinterpret_cast<uint4*>(row);
+#pragma unroll
+  for (int i = 0; i < W / 4; ++i) dst[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+template <class CU>
+ECCX_DEV void u3_load(U<CU, 1, 3>& x, U<CU, 1, 3>& y, U<CU, 1, 3>& z, const uint32_t* __restrict__ row) {
+  constexpr int N = CU::N;
+  constexpr int W = urow3_words<CU>();
+  uint32_t w[W];
+  const uint4* src = reinterpret_cast<const uint4*>(row);
+#pragma unroll
+  for (int i = 0; i < W / 4; ++i) {
+    const uint4 q = src[i];
+    w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) { x.v[i] = w[i]; y.v[i] = w[N + i]; z.v[i] = w[2 * N + i]; }
+}
+
 // 2P.  a = -3 (dbl-2001-b with Z3 = 2YZ): 4 products + 4 squares; a = 0 (dbl-2009-l): 2
 // products + 5 squares.  The typed operations insert a weak reduction wherever an operand's
 // bounds require one; the comments give the (K, V) bounds for P-256, where none is inserted
@@ -233,7 +263,6 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_var_uns
   constexpr int SB = CS::SB;
   constexpr int NWIN = (8 * SB + 1 + 4) / 5;
   constexpr int W5 = urow_words<CU>();
-  constexpr int W3 = row_words<L>();
   uint32_t* slab = scratch + ((size_t)blockIdx.x * FAST_TABLE_ROWS * WG + threadIdx.x) * (size_t)W5;
   auto row = [&](uint32_t e) { return slab + (size_t)e * WG * W5; };
   for (size_t base = (size_t)blockIdx.x * WG; base < n; base += (size_t)gridDim.x * WG) {
@@ -364,11 +393,7 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_var_uns
     }
     if constexpr (FUSED) ucomb_accumulate<CU>(q, base_scalars + idx * (size_t)SB, utable);
     if (active) {
-      Pt<CS> res;  // the saturated field's canonical limbs, as k_batch_to_affine takes them
-      u_to_sat_mont<CU>(res.x, q.x);
-      u_to_sat_mont<CU>(res.y, q.y);
-      u_to_sat_mont<CU>(res.z, q.z);
-      row_store<CS>(rows_out + idx * (size_t)W3, res);
+      u3_store<CU>(rows_out + idx * (size_t)urow3_words<CU>(), q.x, q.y, u_fit<1, 3>(q.z));
       flags[idx] = rejected ? 2 : 0;
     }
   }
@@ -481,9 +506,7 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_base_un
                                                                                   uint32_t* __restrict__ rows_out,
                                                                                   uint8_t* __restrict__ flags) {
   using CS = typename CU::Sat;
-  constexpr int L = CS::L;
   constexpr int SB = CS::SB;
-  constexpr int W3 = row_words<L>();
   for (size_t base = (size_t)blockIdx.x * WG; base < n; base += (size_t)gridDim.x * WG) {
     const size_t gid = base + threadIdx.x;
     const bool active = gid < n;
@@ -498,11 +521,7 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_base_un
     u_set_zero(q.z);  // infinity
     ucomb_accumulate<CU>(q, k, table);
     if (active) {
-      Pt<CS> res;  // the saturated field's canonical limbs, as k_batch_to_affine takes them
-      u_to_sat_mont<CU>(res.x, q.x);
-      u_to_sat_mont<CU>(res.y, q.y);
-      u_to_sat_mont<CU>(res.z, q.z);
-      row_store<CS>(rows_out + idx * (size_t)W3, res);
+      u3_store<CU>(rows_out + idx * (size_t)urow3_words<CU>(), q.x, q.y, u_fit<1, 3>(q.z));
       flags[idx] = 0;
     }
   }
@@ -591,11 +610,7 @@ __global__ void __launch_bounds__(WG, 4) k_x25519_ladder_unsat(size_t n, const u
       u_select(z2, sw, z3, b);
     }
     if (active) {
-      Pt<CS> row;
-      u_to_canonical<CU>(row.x, x2);
-      row.y = row.x;
-      u_to_canonical<CU>(row.z, z2);
-      row_store<CS>(rows_out + idx * (size_t)row_words<L>(), row);
+      u3_store<CU>(rows_out + idx * (size_t)urow3_words<CU>(), x2, x2, z2);
       flags[idx] = 0;
     }
   }
@@ -680,8 +695,6 @@ template <class CU>
 __global__ void __launch_bounds__(WG, 4) k_ed_scalarmul_base_unsat(size_t n, const uint8_t* __restrict__ scalars,
                                                                    const uint32_t* __restrict__ table,
                                                                    uint32_t* __restrict__ rows_out, uint8_t* __restrict__ flags) {
-  using CS = typename CU::Sat;
-  constexpr int L = CS::L;
   using T = U<CU, 1, 3>;
   for (size_t base = (size_t)blockIdx.x * WG; base < n; base += (size_t)gridDim.x * WG) {
     const size_t gid = base + threadIdx.x;
@@ -693,11 +706,7 @@ __global__ void __launch_bounds__(WG, 4) k_ed_scalarmul_base_unsat(size_t n, con
     qy.v[0] = 1; qz.v[0] = 1;
     ued_comb_accumulate<CU>(qx, qy, qz, qt, k, table);
     if (active) {
-      Pt<CS> row;
-      u_to_canonical<CU>(row.x, qx);
-      u_to_canonical<CU>(row.y, qy);
-      u_to_canonical<CU>(row.z, qz);
-      row_store<CS>(rows_out + idx * (size_t)row_words<L>(), row);
+      u3_store<CU>(rows_out + idx * (size_t)urow3_words<CU>(), qx, qy, qz);
       flags[idx] = 0;
     }
   }
@@ -914,11 +923,7 @@ __global__ void __launch_bounds__(WG, 4) k_ed_scalarmul_var_unsat(size_t n, cons
     }
     if constexpr (FUSED) ued_comb_accumulate<CU>(q.x, q.y, q.z, q.t, base_scalars + idx * 32, utable);
     if (active) {
-      Pt<CS> res;
-      u_to_canonical<CU>(res.x, q.x);
-      u_to_canonical<CU>(res.y, q.y);
-      u_to_canonical<CU>(res.z, q.z);
-      row_store<CS>(rows_out + idx * (size_t)row_words<L>(), res);
+      u3_store<CU>(rows_out + idx * (size_t)urow3_words<CU>(), q.x, q.y, q.z);
       flags[idx] = rejected ? 2 : 0;
     }
   }
@@ -1017,32 +1022,9 @@ ECCX_DEV void upt_dbl(UPt<CU>& r, const UPt<CU>& p) {
 }
 
 template <class CU>
-constexpr int urow3_words() { return ((3 * CU::N + 3) / 4) * 4; }
+ECCX_DEV void upt_store(uint32_t* __restrict__ row, const UPt<CU>& p) { u3_store<CU>(row, p.x, p.y, p.z); }
 template <class CU>
-ECCX_DEV void upt_store(uint32_t* __restrict__ row, const UPt<CU>& p) {
-  constexpr int N = CU::N;
-  constexpr int W = urow3_words<CU>();
-  uint32_t w[W];
-#pragma unroll
-  for (int i = 0; i < W; ++i) w[i] = i < N ? p.x.v[i] : (i < 2 * N ? p.y.v[i - N] : (i < 3 * N ? p.z.v[i - 2 * N] : 0u));
-  uint4* dst = reinterpret_cast<uint4*>(row);
-#pragma unroll
-  for (int i = 0; i < W / 4; ++i) dst[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
-}
-template <class CU>
-ECCX_DEV void upt_load(UPt<CU>& p, const uint32_t* __restrict__ row) {
-  constexpr int N = CU::N;
-  constexpr int W = urow3_words<CU>();
-  uint32_t w[W];
-  const uint4* src = reinterpret_cast<const uint4*>(row);
-#pragma unroll
-  for (int i = 0; i < W / 4; ++i) {
-    const uint4 q = src[i];
-    w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w;
-  }
-#pragma unroll
-  for (int i = 0; i < N; ++i) { p.x.v[i] = w[i]; p.y.v[i] = w[N + i]; p.z.v[i] = w[2 * N + i]; }
-}
+ECCX_DEV void upt_load(UPt<CU>& p, const uint32_t* __restrict__ row) { u3_load<CU>(p.x, p.y, p.z, row); }
 
 template <class CU>
 __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_var_mirror_unsat(
@@ -1155,8 +1137,6 @@ __global__ void __launch_bounds__(ED_LDS_BLOCK) k_ed_scalarmul_base_lds6(size_t 
                                                                          const uint32_t* __restrict__ table,
                                                                          uint32_t* __restrict__ rows_out,
                                                                          uint8_t* __restrict__ flags) {
-  using CS = typename CU::Sat;
-  constexpr int L = CS::L;
   constexpr int N = CU::N;
   constexpr int EW = ED_LDS_ENTRY_WORDS;
   static_assert(3 * N <= EW, "entry layout");
@@ -1203,12 +1183,106 @@ __global__ void __launch_bounds__(ED_LDS_BLOCK) k_ed_scalarmul_base_lds6(size_t 
       ued_add_niels<CU, 2, 4>(qx, qy, qz, qt, ym, yp, t2);
     }
     if (active) {
-      Pt<CS> row;
-      u_to_canonical<CU>(row.x, qx);
-      u_to_canonical<CU>(row.y, qy);
-      u_to_canonical<CU>(row.z, qz);
-      row_store<CS>(rows_out + idx * (size_t)row_words<L>(), row);
+      u3_store<CU>(rows_out + idx * (size_t)urow3_words<CU>(), qx, qy, qz);
       flags[idx] = 0;
+    }
+  }
+}
+
+// ---- batched normalisation on the unsaturated field ----------------------------------------------
+// Point::to_affine (projective.rs:655-682; curve25519.rs:663-666, :529-532) for a whole batch of
+// rows written by the kernels above (X, Y, Z as tight digits of the working form).  Thread t of a
+// workgroup handles units tile + u*WG + t, u = 0..U-1, with ONE inversion (Montgomery's trick),
+// by division steps (inv_gcd.hpp).  Modes as for k_batch_to_affine (kernels_fast.hpp):
+//   NORM_JACOBIAN     x = X/Z^2, y = Y/Z^3, big-endian bytes; Z = 0 (all-zero limbs) is infinity
+//   NORM_EDWARDS      x = X/Z, y = Y/Z, little-endian bytes, flag 1 = neutral element
+//   NORM_MONTGOMERY_U u = X/Z with 0 for Z = 0 (mod p), 32 little-endian bytes, flag 1 = zero result
+// flags[i] on entry: 2 marks a rejected input (kept, zero output).
+template <class CU, int MODE, int UN>
+__global__ void __launch_bounds__(WG) k_batch_to_affine_unsat(size_t n, const uint32_t* __restrict__ rows,
+                                                              uint8_t* __restrict__ out, uint8_t* __restrict__ flags) {
+  using CS = typename CU::Sat;
+  constexpr int L = CS::L;
+  constexpr int FB = CS::FB;
+  constexpr int W3 = urow3_words<CU>();
+  using T = U<CU, 1, 3>;
+  static_assert(MODE == NORM_JACOBIAN || MODE == NORM_EDWARDS || MODE == NORM_MONTGOMERY_U, "mode");
+  const size_t tile_units = (size_t)WG * UN;
+  for (size_t tile = (size_t)blockIdx.x * tile_units; tile < n; tile += (size_t)gridDim.x * tile_units) {
+    T one;
+#pragma unroll
+    for (int i = 0; i < CU::N; ++i) one.v[i] = CU::ONE[i];
+    auto z_present = [&](const T& z) {
+      if constexpr (MODE == NORM_MONTGOMERY_U) return !u_is_zero_mod_p(u_reduce(z));  // any multiple of p
+      else return !u_limbs_all_zero(z);
+    };
+    T pre[UN];  // prefix products of the (substituted) Z values
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const size_t i = tile + (size_t)u * WG + threadIdx.x;
+      T x, y, z = one;
+      if (i < n) {
+        u3_load<CU>(x, y, z, rows + i * (size_t)W3);
+        if (!z_present(z)) z = one;  // z_inverse_ct substitutes 1 (projective.rs:655-659)
+      }
+      if (u == 0) pre[0] = z;
+      else pre[u] = u_fit<1, 3>(u_mul(pre[u - 1], z));
+    }
+    T inv;
+    {
+      Fe<L> c;
+      u_to_canonical<CU>(c, pre[UN - 1]);
+      fe_inv_gcd<CS>(c, c);
+      inv = u_as<1, 3>(u_to_mont<CU>(c));
+    }
+#pragma unroll
+    for (int u = UN - 1; u >= 0; --u) {
+      const size_t i = tile + (size_t)u * WG + threadIdx.x;
+      T x = one, y = one, z = one;
+      bool present = false;
+      if (i < n) {
+        u3_load<CU>(x, y, z, rows + i * (size_t)W3);
+        present = z_present(z);
+        if (!present) z = one;
+      }
+      T zi;
+      if (u > 0) {
+        zi = u_fit<1, 3>(u_mul(inv, pre[u - 1]));
+        inv = u_fit<1, 3>(u_mul(inv, z));
+      } else {
+        zi = inv;
+      }
+      Fe<L> ax, ay;
+      if constexpr (MODE == NORM_JACOBIAN) {
+        auto zi2 = u_sqr(zi);
+        u_to_canonical<CU>(ax, u_mul(x, zi2));
+        u_to_canonical<CU>(ay, u_mul(y, u_mul(zi2, zi)));
+      } else {
+        u_to_canonical<CU>(ax, u_mul(x, zi));
+        if constexpr (MODE == NORM_EDWARDS) u_to_canonical<CU>(ay, u_mul(y, zi));
+      }
+      if (i < n) {
+        const bool rejected = flags[i] == 2;
+        if constexpr (MODE == NORM_MONTGOMERY_U) {
+          if (!present) fe_zero<CS>(ax);
+          fe_store_le<CS>(out + i * (size_t)FB, ax);
+          flags[i] = fe_is_zero<CS>(ax) ? 1 : 0;
+        } else if constexpr (MODE == NORM_EDWARDS) {
+          bool neutral = fe_is_zero<CS>(ax);
+#pragma unroll
+          for (int k = 0; k < L; ++k) neutral = neutral && (ay.v[k] == (k == 0 ? 1u : 0u));
+          if (rejected) { fe_zero<CS>(ax); fe_zero<CS>(ay); }
+          fe_store_le<CS>(out + i * (size_t)(2 * FB), ax);
+          fe_store_le<CS>(out + i * (size_t)(2 * FB) + FB, ay);
+          flags[i] = rejected ? 2 : (neutral ? 1 : 0);
+        } else {
+          const bool ok = present && !rejected;
+          if (!ok) { fe_zero<CS>(ax); fe_zero<CS>(ay); }
+          fe_store_be<CS>(out + i * (size_t)(2 * FB), ax);
+          fe_store_be<CS>(out + i * (size_t)(2 * FB) + FB, ay);
+          flags[i] = rejected ? 2 : (present ? 0 : 1);
+        }
+      }
     }
   }
 }
