@@ -105,14 +105,14 @@ WORKLOADS = {
 # read from inside this process, so the figure is the committed measurement of this very
 # workload, not a live one; null where no profile has been taken.
 MEASURED_TRAFFIC = {
-    "p256r1_var_2^20": {"bytes": 2 * (6785633645 + 93791160) + 3669083030 + 70265624,
-                        "fetch_raw": 6785633645 + 93791160, "write": 3669083030 + 70265624,
+    "p256r1_var_2^20": {"bytes": 2 * (6802012096 + 109864632) + 3686706116 + 70264824,
+                        "fetch_raw": 6802012096 + 109864632, "write": 3686706116 + 70264824,
                         "source": "profiles/r01_p256r1_var_u29.json"},
-    "ed25519_base_2^20": {"bytes": 2 * (1115831200 + 95152722) + 101867882 + 103896768,
-                          "fetch_raw": 1115831200 + 95152722, "write": 101867882 + 103896768,
+    "ed25519_base_2^20": {"bytes": 2 * (1132189418 + 108917632) + 118712629 + 70274916,
+                          "fetch_raw": 1132189418 + 108917632, "write": 118712629 + 70274916,
                           "source": "profiles/r01_ed25519_base.json"},
-    "x25519_2^20": {"bytes": 2 * (31359716 + 92948388) + 101712000 + 70254674,
-                    "fetch_raw": 31359716 + 92948388, "write": 101712000 + 70254674,
+    "x25519_2^20": {"bytes": 2 * (31777600 + 106718518) + 118492877 + 36700406,
+                    "fetch_raw": 31777600 + 106718518, "write": 118492877 + 36700406,
                     "source": "profiles/r01_x25519.json"},
 }
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
