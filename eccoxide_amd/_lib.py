@@ -29,6 +29,11 @@ SYMBOLS = {
     "eccx_point_add": (c_int, [c_void_p, c_int, c_size_t, _u8p, _u8p, _u8p, _u8p, _u8p, _u8p, c_uint32]),
     "eccx_double_scalarmul": (c_int, [c_void_p, c_int, c_size_t, _u8p, _u8p, _u8p, _u8p, _u8p, c_uint32]),
     "eccx_x25519": (c_int, [c_void_p, c_size_t, _u8p, _u8p, _u8p, _u8p, c_uint32]),
+    "eccx_compressed_bytes": (c_int, [c_int]),
+    "eccx_point_decompress": (c_int, [c_void_p, c_int, c_size_t, _u8p, _u8p, _u8p, c_uint32]),
+    "eccx_point_compress": (c_int, [c_void_p, c_int, c_size_t, _u8p, _u8p, _u8p, c_uint32]),
+    "eccx_point_decompress_dev": (c_int, [c_void_p, c_int, c_size_t, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p]),
+    "eccx_point_compress_dev": (c_int, [c_void_p, c_int, c_size_t, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p]),
     "eccx_double_scalarmul_dev": (c_int, [c_void_p, c_int, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p]),
     "eccx_x25519_dev": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p]),
     "eccx_comb_table": (c_int, [c_void_p, c_int, _u8p]),

@@ -111,6 +111,33 @@ int norm_grid(const eccx_ctx* ctx, size_t n) {
   return (int)std::max<size_t>(1, std::min(tiles, (size_t)ctx->cus * 4));
 }
 
+// order r of bls12_381_g1, big-endian (src/params/bls12_381.rs ORDER_BYTES): the scalar of the
+// subgroup membership test [r]P = infinity
+const uint8_t BLS12_381_ORDER[32] = {0x73, 0xed, 0xa7, 0x53, 0x29, 0x9d, 0x7d, 0x48, 0x33, 0x39, 0xd8, 0x08, 0x09, 0xa1, 0xd8, 0x05,
+                                     0x53, 0xbd, 0xa4, 0x02, 0xff, 0xfe, 0x5b, 0xfe, 0xff, 0xff, 0xff, 0xff, 0x00, 0x00, 0x00, 0x01};
+
+// out[i] = row for every i (rows of 16 bytes or a multiple)
+__global__ void k_replicate_row(size_t n, int row_quads, const uint4* __restrict__ row, uint4* __restrict__ out) {
+  const size_t total = n * (size_t)row_quads;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = row[i % row_quads];
+}
+// a decoded point whose multiple by the group order is not the point at infinity is rejected
+__global__ void k_reject_outside_subgroup(size_t n, const uint8_t* __restrict__ order_mul_flags, uint8_t* __restrict__ flags,
+                                          uint8_t* __restrict__ out, int point_bytes) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    if (flags[i] == 0 && order_mul_flags[i] == 0) {
+      flags[i] = 2;
+      for (int k = 0; k < point_bytes; ++k) out[i * (size_t)point_bytes + k] = 0;
+    }
+  }
+}
+
+int flat_grid(const eccx_ctx* ctx, size_t n) {
+  size_t need = (n + eccx::LAUNCH_WG - 1) / eccx::LAUNCH_WG;
+  return (int)std::max<size_t>(1, std::min(need, (size_t)ctx->cus * 8));
+}
+
 // Variable base.  mirror = run the reference-mirroring kernel (homogeneous RCB formulas,
 // un-normalised X:Y:Z available); otherwise the fast Jacobian kernel + batched
 // normalisation where the curve has one.
@@ -596,6 +623,109 @@ int eccx_point_add(eccx_ctx* ctx, int curve, size_t n, const uint8_t* a, const u
   if ((e = hipMemcpyAsync(flags, d[5], n, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) return fail(e, "hipMemcpyAsync");
   if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(e, "hipStreamSynchronize");
   cleanup();
+  return ECCX_OK;
+}
+
+int eccx_compressed_bytes(int curve) {
+  const CurveOps* ops = ops_of(curve);
+  return ops ? ops->enc_bytes : ECCX_ERR_CURVE;
+}
+
+int eccx_point_decompress_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_enc, void* d_out, void* d_flags,
+                              uint32_t opts, void* stream) {
+  const CurveOps* ops = ops_of(curve);
+  if (!ctx) return ECCX_ERR_ARG;
+  if (!ops) return ECCX_ERR_CURVE;
+  if (n == 0) return ECCX_OK;
+  if (!d_enc || !d_out || !d_flags) return ECCX_ERR_ARG;
+  // the sec2 curves have cofactor 1 (nothing to check); decode_point makes no such test
+  if ((opts & ECCX_CHECK_SUBGROUP) && ops->info.edwards) return ECCX_ERR_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  uint8_t* out = static_cast<uint8_t*>(d_out);
+  uint8_t* flags = static_cast<uint8_t*>(d_flags);
+  HIP_TRY(ctx, ops->decompress(flat_grid(ctx, n), s, n, static_cast<const uint8_t*>(d_enc), out, flags));
+  if ((opts & ECCX_CHECK_SUBGROUP) && curve == ECCX_BLS12_381_G1) {
+    // [r]P through the variable-base kernel; rejected records hold (0, 0), whose multiple is
+    // some garbage the merge ignores
+    const size_t pb = 2 * (size_t)ops->info.fb;
+    DevMem mem;
+    uint8_t *d_k = nullptr, *d_row = nullptr, *d_mul = nullptr, *d_mul_flags = nullptr;
+    HIP_TRY(ctx, mem.alloc(&d_k, n * 32));
+    HIP_TRY(ctx, mem.alloc(&d_row, 32));
+    HIP_TRY(ctx, mem.alloc(&d_mul, n * pb));
+    HIP_TRY(ctx, mem.alloc(&d_mul_flags, n));
+    HIP_TRY(ctx, hipMemcpyAsync(d_row, BLS12_381_ORDER, 32, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_replicate_row, dim3(flat_grid(ctx, 2 * n)), dim3(eccx::LAUNCH_WG), 0, s, n, 2,
+                       reinterpret_cast<const uint4*>(d_row), reinterpret_cast<uint4*>(d_k));
+    HIP_TRY(ctx, hipGetLastError());
+    int rc = launch_var(ctx, ops, n, d_k, out, d_mul, d_mul_flags, nullptr, 0u, false, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_reject_outside_subgroup, dim3(flat_grid(ctx, n)), dim3(eccx::LAUNCH_WG), 0, s, n, d_mul_flags, flags,
+                       out, (int)pb);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(s));  // the temporaries go away with this scope
+  }
+  return ECCX_OK;
+}
+
+int eccx_point_compress_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_xy, const void* d_inf, void* d_out,
+                            uint32_t opts, void* stream) {
+  const CurveOps* ops = ops_of(curve);
+  if (!ctx) return ECCX_ERR_ARG;
+  if (!ops) return ECCX_ERR_CURVE;
+  if (n == 0) return ECCX_OK;
+  if (!d_xy || !d_out) return ECCX_ERR_ARG;
+  (void)opts;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, ops->compress(flat_grid(ctx, n), static_cast<hipStream_t>(stream), n, static_cast<const uint8_t*>(d_xy),
+                             static_cast<const uint8_t*>(d_inf), static_cast<uint8_t*>(d_out)));
+  return ECCX_OK;
+}
+
+int eccx_point_decompress(eccx_ctx* ctx, int curve, size_t n, const uint8_t* enc, uint8_t* out, uint8_t* flags,
+                          uint32_t opts) {
+  const CurveOps* ops = ops_of(curve);
+  if (!ctx) return ECCX_ERR_ARG;
+  if (!ops) return ECCX_ERR_CURVE;
+  if (n == 0) return ECCX_OK;
+  if (!enc || !out || !flags) return ECCX_ERR_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t eb = (size_t)ops->enc_bytes, pb = 2 * (size_t)ops->info.fb;
+  DevMem mem;
+  uint8_t *d_enc = nullptr, *d_out = nullptr, *d_flags = nullptr;
+  HIP_TRY(ctx, mem.alloc(&d_enc, n * eb));
+  HIP_TRY(ctx, mem.alloc(&d_out, n * pb));
+  HIP_TRY(ctx, mem.alloc(&d_flags, n));
+  HIP_TRY(ctx, hipMemcpyAsync(d_enc, enc, n * eb, hipMemcpyHostToDevice, ctx->stream));
+  int rc = eccx_point_decompress_dev(ctx, curve, n, d_enc, d_out, d_flags, opts, ctx->stream);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(out, d_out, n * pb, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(flags, d_flags, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return ECCX_OK;
+}
+
+int eccx_point_compress(eccx_ctx* ctx, int curve, size_t n, const uint8_t* xy, const uint8_t* inf, uint8_t* out,
+                        uint32_t opts) {
+  const CurveOps* ops = ops_of(curve);
+  if (!ctx) return ECCX_ERR_ARG;
+  if (!ops) return ECCX_ERR_CURVE;
+  if (n == 0) return ECCX_OK;
+  if (!xy || !out) return ECCX_ERR_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t eb = (size_t)ops->enc_bytes, pb = 2 * (size_t)ops->info.fb;
+  DevMem mem;
+  uint8_t *d_xy = nullptr, *d_inf = nullptr, *d_out = nullptr;
+  HIP_TRY(ctx, mem.alloc(&d_xy, n * pb));
+  if (inf) HIP_TRY(ctx, mem.alloc(&d_inf, n));
+  HIP_TRY(ctx, mem.alloc(&d_out, n * eb));
+  HIP_TRY(ctx, hipMemcpyAsync(d_xy, xy, n * pb, hipMemcpyHostToDevice, ctx->stream));
+  if (inf) HIP_TRY(ctx, hipMemcpyAsync(d_inf, inf, n, hipMemcpyHostToDevice, ctx->stream));
+  int rc = eccx_point_compress_dev(ctx, curve, n, d_xy, d_inf, d_out, opts, ctx->stream);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(out, d_out, n * eb, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return ECCX_OK;
 }
 

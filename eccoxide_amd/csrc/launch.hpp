@@ -67,6 +67,11 @@ struct CurveOps {
   hipError_t (*lds_convert)(hipStream_t s, size_t entries, const uint8_t* affine, uint32_t* table);
   hipError_t (*var_fused)(int grid, hipStream_t s, size_t n, const uint8_t* u2, const uint8_t* q, uint32_t* rows,
                           uint8_t* flags, uint32_t* scratch, uint32_t opts, const uint8_t* u1, const uint32_t* utable);
+  // wire formats (kernels_codec.hpp): enc_bytes per compressed point; decompress writes x||y and
+  // flags 0 point / 1 infinity / 2 rejected; compress takes x||y and optional infinity flags
+  int enc_bytes;
+  hipError_t (*decompress)(int grid, hipStream_t s, size_t n, const uint8_t* enc, uint8_t* out, uint8_t* flags);
+  hipError_t (*compress)(int grid, hipStream_t s, size_t n, const uint8_t* xy, const uint8_t* inf, uint8_t* out);
 };
 // units normalised per lane with one inversion: 16 where the prefix products fit the register
 // file (8-limb fields), 8 above

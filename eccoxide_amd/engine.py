@@ -19,6 +19,7 @@ TABLE_IN_LDS = 1 << 2
 TABLE_IN_L2 = 1 << 3
 X25519_RAW_LADDER = 1 << 4
 SUBTRACT = 1 << 5
+CHECK_SUBGROUP = 1 << 6
 FLAG_FINITE, FLAG_INFINITY, FLAG_REJECTED = 0, 1, 2
 
 
@@ -154,6 +155,78 @@ class Engine:
                                              (SUBTRACT if subtract else 0) | (VALIDATE_POINTS if validate else 0))
         self._check(rc)
         return out.raw[: n * 2 * fb], flags.raw[:n]
+
+    def compressed_bytes(self, curve) -> int:
+        """Bytes per compressed point: FB + 1 (SEC1), 48 (zcash G1), 32 (RFC 8032)."""
+        return self._lib.eccx_compressed_bytes(curve_id(curve))
+
+    def point_decompress(self, curve, enc: bytes, *, check_subgroup: bool = False):
+        """Compressed encodings -> (n x 2FB affine x||y, flags): 0 point, 1 infinity encoding, 2 rejected.
+        SEC1 for the sec2 curves, zcash for bls12_381_g1 (check_subgroup=True: from_compressed,
+        else from_compressed_oncurve_only), RFC 8032 for ed25519."""
+        cid = curve_id(curve)
+        fb, eb = field_bytes(cid), self.compressed_bytes(cid)
+        if len(enc) % eb:
+            raise ValueError(f"enc must be n x {eb} bytes")
+        n = len(enc) // eb
+        out = ctypes.create_string_buffer(max(1, n * 2 * fb))
+        flags = ctypes.create_string_buffer(max(1, n))
+        self._check(self._lib.eccx_point_decompress(self._ctx, cid, n, enc, out, flags, CHECK_SUBGROUP if check_subgroup else 0))
+        return out.raw[: n * 2 * fb], flags.raw[:n]
+
+    def point_compress(self, curve, xy: bytes, inf: Optional[bytes] = None) -> bytes:
+        """Affine x||y records (+ optional infinity flags) -> compressed encodings."""
+        cid = curve_id(curve)
+        fb, eb = field_bytes(cid), self.compressed_bytes(cid)
+        if len(xy) % (2 * fb) or (inf is not None and len(inf) != len(xy) // (2 * fb)):
+            raise ValueError("xy must be n x 2FB bytes and inf n bytes")
+        n = len(xy) // (2 * fb)
+        out = ctypes.create_string_buffer(max(1, n * eb))
+        self._check(self._lib.eccx_point_compress(self._ctx, cid, n, xy, inf, out, 0))
+        return out.raw[: n * eb]
+
+    def point_decompress_t(self, curve, enc, out=None, flags=None, *, check_subgroup: bool = False,
+                           stream: Optional[int] = None):
+        """Device-tensor form of point_decompress (torch.uint8 CUDA tensors)."""
+        import torch
+
+        cid = curve_id(curve)
+        fb, eb = field_bytes(cid), self.compressed_bytes(cid)
+        n = enc.numel() // eb
+        if out is None:
+            out = torch.empty((n, 2 * fb), dtype=torch.uint8, device=enc.device)
+        if flags is None:
+            flags = torch.empty((n,), dtype=torch.uint8, device=enc.device)
+        for t in (enc, out, flags):
+            if not (t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()):
+                raise ValueError("tensors must be contiguous torch.uint8 CUDA tensors")
+        if enc.numel() != n * eb or out.numel() != n * 2 * fb or flags.numel() != n:
+            raise ValueError("enc, out and flags must describe the same number of units")
+        if stream is None:
+            stream = torch.cuda.current_stream(enc.device).cuda_stream
+        self._check(self._lib.eccx_point_decompress_dev(self._ctx, cid, n, enc.data_ptr(), out.data_ptr(), flags.data_ptr(),
+                                                        CHECK_SUBGROUP if check_subgroup else 0, stream))
+        return out, flags
+
+    def point_compress_t(self, curve, xy, inf=None, out=None, *, stream: Optional[int] = None):
+        """Device-tensor form of point_compress (torch.uint8 CUDA tensors)."""
+        import torch
+
+        cid = curve_id(curve)
+        fb, eb = field_bytes(cid), self.compressed_bytes(cid)
+        n = xy.numel() // (2 * fb)
+        if out is None:
+            out = torch.empty((n, eb), dtype=torch.uint8, device=xy.device)
+        for t in (xy, out) + ((inf,) if inf is not None else ()):
+            if not (t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()):
+                raise ValueError("tensors must be contiguous torch.uint8 CUDA tensors")
+        if xy.numel() != n * 2 * fb or out.numel() != n * eb or (inf is not None and inf.numel() != n):
+            raise ValueError("xy, inf and out must describe the same number of units")
+        if stream is None:
+            stream = torch.cuda.current_stream(xy.device).cuda_stream
+        self._check(self._lib.eccx_point_compress_dev(self._ctx, cid, n, xy.data_ptr(),
+                                                      inf.data_ptr() if inf is not None else None, out.data_ptr(), 0, stream))
+        return out
 
     def x25519(self, scalars: bytes, u: Optional[bytes] = None, *, raw_ladder: bool = False):
         """X25519 over a batch: returns (n x 32 little-endian u-coordinates, flags).

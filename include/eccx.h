@@ -86,7 +86,8 @@ enum {
                                      DESIGN.md for the numbers. */
   ECCX_TABLE_IN_L2 = 1u << 3,    /* fixed base: the reference's 4-bit comb, table read through L1/L2 */
   ECCX_X25519_RAW_LADDER = 1u << 4, /* eccx_x25519: raw MontgomeryPoint::scale_bytes semantics */
-  ECCX_SUBTRACT = 1u << 5          /* eccx_point_add: compute a - b */
+  ECCX_SUBTRACT = 1u << 5,         /* eccx_point_add: compute a - b */
+  ECCX_CHECK_SUBGROUP = 1u << 6    /* eccx_point_decompress, bls12_381_g1: reject points outside G1 */
 };
 
 /* flag values written per unit */
@@ -169,6 +170,37 @@ int eccx_x25519(eccx_ctx* ctx, size_t n, const uint8_t* scalars, const uint8_t* 
                 uint32_t opts);
 int eccx_x25519_dev(eccx_ctx* ctx, size_t n, const void* d_scalars, const void* d_u, void* d_out, void* d_flags,
                     uint32_t opts, void* stream);
+
+/* Point wire formats, batched: compressed encodings <-> the affine x||y records above.
+ *   p256r1 / p384r1 / p521r1  SEC1 compressed, FB + 1 bytes: 0x02 | (y odd), then x big-endian;
+ *                             a record of FB + 1 zero bytes stands for the point at infinity.
+ *                             Byte form of PointAffine::compress / decompress, which trade in
+ *                             (x, Sign) with Sign::Negative = y odd (src/curve/affine.rs:23-58,
+ *                             src/curve/fiat/curve_macros.rs:211-223, field_macros.rs:557-565).
+ *   bls12_381_g1              zcash compressed, 48 bytes (src/curve/bls12_381/serialize.rs:
+ *                             253-262 to_compressed, :321-335 from_compressed_oncurve_only; with
+ *                             ECCX_CHECK_SUBGROUP :299-313 from_compressed, whose membership
+ *                             test [r]P = infinity runs through the variable-base kernel).
+ *   edwards25519              RFC 8032, 32 bytes: y little-endian, low bit of x in bit 255
+ *                             (src/protocol/ed25519.rs:27-59 encode_point / decode_point).
+ * eccx_point_decompress: enc n x eccx_compressed_bytes(curve) -> out n x 2FB, flags n:
+ *   0 point, 1 the encoding of the point at infinity (Weierstrass), 2 rejected -- bad prefix or
+ *   flag bits, coordinate not below p, no point with this coordinate, (ed25519) x = 0 with the
+ *   sign bit set, (ECCX_CHECK_SUBGROUP) not in G1.  Records flagged 1 or 2 are zero-filled.
+ * eccx_point_compress: xy n x 2FB canonical coordinates, inf NULL or n bytes (non-zero = point
+ *   at infinity, as the flags of the scalar multiplications report it) -> out n x
+ *   eccx_compressed_bytes(curve).
+ * The _dev forms take device memory and enqueue on `stream` without synchronising, so
+ * decompress -> scalarmul -> compress chains stay on the GPU. */
+int eccx_compressed_bytes(int curve);
+int eccx_point_decompress(eccx_ctx* ctx, int curve, size_t n, const uint8_t* enc, uint8_t* out, uint8_t* flags,
+                          uint32_t opts);
+int eccx_point_compress(eccx_ctx* ctx, int curve, size_t n, const uint8_t* xy, const uint8_t* inf, uint8_t* out,
+                        uint32_t opts);
+int eccx_point_decompress_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_enc, void* d_out, void* d_flags,
+                              uint32_t opts, void* stream);
+int eccx_point_compress_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_xy, const void* d_inf, void* d_out,
+                            uint32_t opts, void* stream);
 
 /* The fixed-base comb table in the reference's on-disk layout (src/params/comb/<curve>.rs):
  * NW x 15 entries (j+1)*16^i*G as x||y, FB bytes each, big-endian (little-endian for

@@ -545,3 +545,141 @@ def scalarmul_base_bytes(curve: str, scalars: bytes) -> Tuple[bytes, bytes]:
                 out += a[0].to_bytes(c.fb, "big") + a[1].to_bytes(c.fb, "big")
                 inf.append(0)
     return bytes(out), bytes(inf)
+
+
+# ---- point wire formats ----------------------------------------
+# Statuses of the batched decoders: 0 point, 1 the encoding of the point at infinity, 2 rejected.
+CODEC_OK, CODEC_INFINITY, CODEC_INVALID = 0, 1, 2
+
+
+def ref_sqrt_p3mod4(p: int, a: int) -> Optional[int]:
+    """sqrt for p = 3 (mod 4): the candidate a^((p+1)/4), present only if it squares back to a
+    (sec2/p256r1.rs:68-84, p384r1.rs:71-, p521r1.rs:126-131, bls12_381/fp.rs:64-68)."""
+    r = pow(a, (p + 1) // 4, p)
+    return r if r * r % p == a % p else None
+
+
+def ref_w_decompress_xy(c: WeierstrassParams, x: int, negative: bool) -> Optional[Tuple[int, int]]:
+    """affine::Point::decompress (src/curve/affine.rs:48-58): y = sqrt(x^3 + a x + b), replaced by
+    -y when its sign (low bit of the canonical value, fiat/field_macros.rs:557-565) is not the
+    requested one."""
+    yy = (x * x * x + c.a * x + c.b) % c.p
+    y = ref_sqrt_p3mod4(c.p, yy)
+    if y is None:
+        return None
+    if bool(y & 1) != negative:
+        y = (-y) % c.p
+    return (x, y)
+
+
+def _bls_is_largest(c: WeierstrassParams, y: int) -> bool:
+    return y > (c.p - 1) // 2  # Fp::is_largest, bls12_381/serialize.rs:143-148
+
+
+def compressed_bytes(curve: str) -> int:
+    if curve == "ed25519":
+        return 32
+    c = WEIERSTRASS[curve]
+    return c.fb if curve == "bls12_381_g1" else c.fb + 1
+
+
+def ref_point_compress(curve: str, P: Affine) -> bytes:
+    """One affine point (None = infinity) -> its compressed encoding.
+    sec2: SEC1 0x02 | (y odd) || x -- the byte form of PointAffine::compress's (x, Sign)
+    (curve_macros.rs:211-213); infinity = FB + 1 zero bytes.
+    bls12_381_g1: to_compressed (serialize.rs:253-262, flags :52-62,103-106); infinity
+    = 0xC0 then zeros (:93-95).  ed25519: encode_point (protocol/ed25519.rs:27-36)."""
+    if curve == "ed25519":
+        return ed_encode_point(ED25519, P)
+    c = WEIERSTRASS[curve]
+    if curve == "bls12_381_g1":
+        if P is None:
+            return bytes([0xC0]) + bytes(c.fb - 1)
+        out = bytearray(P[0].to_bytes(c.fb, "big"))
+        out[0] |= 0x80 | (0x20 if _bls_is_largest(c, P[1]) else 0)
+        return bytes(out)
+    if P is None:
+        return bytes(c.fb + 1)
+    return bytes([2 | (P[1] & 1)]) + P[0].to_bytes(c.fb, "big")
+
+
+def ref_ed_sqrt_div(p: int, u: int, v: int) -> Optional[int]:
+    """FieldElement::sqrt_div (curve25519.rs:246-265): r = u v^3 (u v^7)^((p-5)/8); v r^2 = u:
+    r; v r^2 = -u: i r; else none."""
+    v3 = v * v % p * v % p
+    v7 = v3 * v3 % p * v % p
+    r = u * v3 % p * pow(u * v7 % p, (p - 5) // 8, p) % p
+    check = v * r % p * r % p
+    if check == u % p:
+        return r
+    if check == (-u) % p:
+        return r * pow(2, (p - 1) // 4, p) % p
+    return None
+
+
+def ref_point_decompress(curve: str, enc: bytes, check_subgroup: bool = False) -> Tuple[Affine, int]:
+    """One encoding -> (point or None, status)."""
+    if curve == "ed25519":
+        c = ED25519
+        sign = enc[31] >> 7  # decode_point, protocol/ed25519.rs:38-59
+        y = int.from_bytes(enc, "little") & ((1 << 255) - 1)
+        if y >= c.p:
+            return None, CODEC_INVALID
+        if sign and y in (1, c.p - 1):
+            return None, CODEC_INVALID
+        yy = y * y % c.p  # Point::decompress, curve25519.rs:772-784
+        x = ref_ed_sqrt_div(c.p, (yy - 1) % c.p, (c.d * yy + 1) % c.p)
+        if x is None:
+            return None, CODEC_INVALID
+        if (x & 1) != sign:
+            x = (-x) % c.p
+        return (x, y), CODEC_OK
+    c = WEIERSTRASS[curve]
+    if curve == "bls12_381_g1":
+        fl = enc[0] & 0xE0  # read_compressed_flags, serialize.rs:109-127
+        x = int.from_bytes(enc, "big") & ((1 << (8 * c.fb - 3)) - 1)
+        if not fl & 0x80:
+            return None, CODEC_INVALID
+        if fl & 0x40:
+            return None, (CODEC_INFINITY if not (fl & 0x20) and x == 0 else CODEC_INVALID)
+        if x >= c.p:
+            return None, CODEC_INVALID
+        P = ref_w_decompress_xy(c, x, False)  # read_compressed_affine, serialize.rs:181-202
+        if P is None:
+            return None, CODEC_INVALID
+        if _bls_is_largest(c, P[1]) != bool(fl & 0x20):
+            P = (P[0], (-P[1]) % c.p)
+        if check_subgroup and affine_mul(c, c.n, P) is not None:  # from_compressed, :299-313
+            return None, CODEC_INVALID
+        return P, CODEC_OK
+    x = int.from_bytes(enc[1:], "big")
+    if enc[0] not in (2, 3):
+        return None, (CODEC_INFINITY if enc[0] == 0 and x == 0 else CODEC_INVALID)
+    if x >= c.p:
+        return None, CODEC_INVALID
+    P = ref_w_decompress_xy(c, x, enc[0] == 3)
+    return (P, CODEC_OK) if P is not None else (None, CODEC_INVALID)
+
+
+def point_compress_bytes(curve: str, xy: bytes, inf: Optional[bytes] = None) -> bytes:
+    """Batch form over the engine's x||y records (little-endian for ed25519)."""
+    fb = CURVES[curve].fb
+    order = "little" if curve == "ed25519" else "big"
+    out = bytearray()
+    for i in range(len(xy) // (2 * fb)):
+        rec = xy[i * 2 * fb:(i + 1) * 2 * fb]
+        P = None if (inf is not None and inf[i]) else (int.from_bytes(rec[:fb], order), int.from_bytes(rec[fb:], order))
+        out += ref_point_compress(curve, P)
+    return bytes(out)
+
+
+def point_decompress_bytes(curve: str, enc: bytes, check_subgroup: bool = False) -> Tuple[bytes, bytes]:
+    fb = CURVES[curve].fb
+    eb = compressed_bytes(curve)
+    order = "little" if curve == "ed25519" else "big"
+    out, flags = bytearray(), bytearray()
+    for i in range(len(enc) // eb):
+        P, st = ref_point_decompress(curve, enc[i * eb:(i + 1) * eb], check_subgroup)
+        out += bytes(2 * fb) if P is None else P[0].to_bytes(fb, order) + P[1].to_bytes(fb, order)
+        flags.append(st)
+    return bytes(out), bytes(flags)

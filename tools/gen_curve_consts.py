@@ -75,7 +75,24 @@ def digits(x, bits, n):
     return [(x >> (bits * i)) & ((1 << bits) - 1) for i in range(n)]
 
 
-def emit_unsat(out, name, sat_name, p, gx, gy, bits, n, kind, extra=(), solinas=(), sparse=False):
+def runs_of(e):
+    """Binary expansion of e from the top bit as (ones, zeros) runs."""
+    segs, b = [], bin(e)[2:]
+    i = 0
+    while i < len(b):
+        j = i
+        while j < len(b) and b[j] == "1":
+            j += 1
+        k = j
+        while k < len(b) and b[k] == "0":
+            k += 1
+        segs.append((j - i, k - j))
+        i = k
+    assert sum(o + z for o, z in segs) == e.bit_length()
+    return segs
+
+
+def emit_unsat(out, name, sat_name, p, gx, gy, bits, n, kind, extra=(), solinas=(), sparse=False, root_exp=0):
     """Constants of the unsaturated representation: n limbs of `bits` bits in 32-bit registers.
     kind 0: Montgomery, R = 2^(bits*n), p = -1 mod 2^bits (reduce with the digits of p + 1)
     kind 1: Montgomery, general p (m = acc * N0B mod 2^bits)
@@ -157,6 +174,21 @@ def emit_unsat(out, name, sat_name, p, gx, gy, bits, n, kind, extra=(), solinas=
     out.append(arr("GY", digits(gy * R % p, bits, n)))
     for cname, val in extra:
         out.append(arr(cname, digits(val * R % p, bits, n)))
+    # exponent of the square-root candidate (point decompression): (p + 1) / 4 for p = 3 mod 4,
+    # (p - 5) / 8 for 2^255 - 19.  As runs of ones and zeros from the top bit (a few long runs
+    # for the Solinas / Mersenne primes: addition chain on x^(2^k - 1)), and as 32-bit words
+    # for the 2-bit-window loop used when the pattern is irregular (BLS12-381).
+    segs = runs_of(root_exp)
+    out.append("  static constexpr int ROOT_BITS = %d;" % root_exp.bit_length())
+    out.append("  static constexpr int ROOT_CHAIN = %d;  // 1: few long runs, use the run chain" % (1 if len(segs) <= 8 else 0))
+    if len(segs) <= 8:
+        out.append("  static constexpr int ROOT_SEGS = %d;" % len(segs))
+        out.append("  static constexpr int ROOT_ONES[%d] = {%s};" % (len(segs), ", ".join(str(o) for o, _ in segs)))
+        out.append("  static constexpr int ROOT_ZEROS[%d] = {%s};" % (len(segs), ", ".join(str(z) for _, z in segs)))
+    else:
+        out.append("  static constexpr int ROOT_SEGS = 0;")
+    nw = (root_exp.bit_length() + 31) // 32
+    out.append("  static constexpr uint32_t ROOT_EXP[%d] = {%s};" % (nw, ", ".join("0x%08xu" % ((root_exp >> (32 * i)) & 0xFFFFFFFF) for i in range(nw))))
     out.append("};")
     out.append("")
 
@@ -180,14 +212,15 @@ def main():
         out.append("")
     bb = lambda i: (("CB", CURVES[i][2]), ("CB3", 3 * CURVES[i][2] % CURVES[i][1]))   # curve constant b and 3b
     emit_unsat(out, "P256U", "P256", CURVES[0][1], CURVES[0][3], CURVES[0][4], 29, 9, 0,
-               solinas=((224, -1), (192, 1), (96, 1)), extra=bb(0))
+               solinas=((224, -1), (192, 1), (96, 1)), extra=bb(0), root_exp=(CURVES[0][1] + 1) // 4)
     emit_unsat(out, "P384U", "P384", CURVES[1][1], CURVES[1][3], CURVES[1][4], 28, 14, 0,
-               solinas=((128, -1), (96, -1), (32, 1)), sparse=True, extra=bb(1))
-    emit_unsat(out, "P521U", "P521", CURVES[2][1], CURVES[2][3], CURVES[2][4], 29, 18, 2, extra=bb(2))
-    emit_unsat(out, "BLS12_381U", "BLS12_381", CURVES[3][1], CURVES[3][3], CURVES[3][4], 28, 14, 1, extra=bb(3))
+               solinas=((128, -1), (96, -1), (32, 1)), sparse=True, extra=bb(1), root_exp=(CURVES[1][1] + 1) // 4)
+    emit_unsat(out, "P521U", "P521", CURVES[2][1], CURVES[2][3], CURVES[2][4], 29, 18, 2, extra=bb(2), root_exp=(CURVES[2][1] + 1) // 4)
+    emit_unsat(out, "BLS12_381U", "BLS12_381", CURVES[3][1], CURVES[3][3], CURVES[3][4], 28, 14, 1, extra=bb(3), root_exp=(CURVES[3][1] + 1) // 4)
     L = 8
     out.append("struct ED25519;")
-    emit_unsat(out, "ED25519U", "ED25519", P25519, ED_GX, ED_GY, 29, 9, 3, extra=(("D2", 2 * ED_D % P25519),))
+    emit_unsat(out, "ED25519U", "ED25519", P25519, ED_GX, ED_GY, 29, 9, 3, extra=(("D2", 2 * ED_D % P25519), ("D", ED_D), ("SQRT_M1", pow(2, (P25519 - 1) // 4, P25519))),
+               root_exp=(P25519 - 5) // 8)
     out.append("struct ED25519 {")
     out.append("  static constexpr int L = 8;")
     out.append("  static constexpr int FB = 32;")
