@@ -78,7 +78,7 @@ hipError_t decompress_(int grid, hipStream_t s, size_t n, const uint8_t* enc, ui
   return hipGetLastError();
 }
 hipError_t compress_(int grid, hipStream_t s, size_t n, const uint8_t* xy, const uint8_t* /*inf: the identity is (0, 1)*/, uint8_t* out) {
-  hipLaunchKernelGGL(k_ed_point_compress<ED25519>, dim3(grid), dim3(WG), 0, s, n, xy, out);
+  hipLaunchKernelGGL((k_point_compress<ED25519, FORMAT_RFC8032>), dim3(grid), dim3(WG), 0, s, n, xy, nullptr, out);
   return hipGetLastError();
 }
 }  // namespace

@@ -27,7 +27,7 @@
 namespace eccx {
 
 enum : uint8_t { CODEC_OK = 0, CODEC_INFINITY = 1, CODEC_INVALID = 2 };
-enum : int { FORMAT_SEC1 = 0, FORMAT_ZCASH = 1 };
+enum : int { FORMAT_SEC1 = 0, FORMAT_ZCASH = 1, FORMAT_RFC8032 = 2 };
 
 template <class CU>
 using UT = U<CU, 1, 3>;
@@ -204,31 +204,63 @@ __global__ void __launch_bounds__(WG) k_point_decompress(size_t n, const uint8_t
   }
 }
 
+// block-wide copy between global memory and LDS: 16 bytes per lane when both sides are aligned
+ECCX_DEV void stage_copy(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, size_t bytes) {
+  size_t done = 0;
+  if ((((uintptr_t)dst | (uintptr_t)src) & 15u) == 0) {
+    const size_t quads = bytes >> 4;
+    for (size_t i = threadIdx.x; i < quads; i += WG) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+    done = quads << 4;
+  }
+  for (size_t i = done + threadIdx.x; i < bytes; i += WG) dst[i] = src[i];
+}
+
 // x||y (+ optional infinity flags) -> enc.  Coordinates are taken as canonical (what every
-// kernel of this library emits and what the reference's types guarantee).
+// kernel of this library emits and what the reference's types guarantee).  Pure byte movement
+// (HBM-bound): a workgroup's records are contiguous on both sides, so they are staged through
+// LDS with 16-byte accesses and only the LDS side sees the odd record sizes (33 / 49 / 67 bytes).
 template <class CS, int FORMAT>
 __global__ void __launch_bounds__(WG) k_point_compress(size_t n, const uint8_t* __restrict__ xy, const uint8_t* __restrict__ inf,
                                                        uint8_t* __restrict__ out) {
   constexpr int L = CS::L;
   constexpr int FB = CS::FB;
+  constexpr int PB = 2 * FB;
   constexpr int EB = enc_bytes<CS, FORMAT>();
-  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n; i += (size_t)gridDim.x * WG) {
-    const uint8_t* __restrict__ p = xy + i * (size_t)(2 * FB);
-    uint8_t* __restrict__ o = out + i * (size_t)EB;
-    const bool is_inf = inf != nullptr && inf[i] != 0;
-    if constexpr (FORMAT == FORMAT_SEC1) {
-      o[0] = is_inf ? 0u : (uint8_t)(2u | (p[2 * FB - 1] & 1u));
-#pragma unroll 4
-      for (int k = 0; k < FB; ++k) o[1 + k] = is_inf ? 0u : p[k];
-    } else {
-      Fe<L> y, yn;
-      fe_load_be<CS>(y, p + FB);
-      fe_neg_canonical<CS>(yn, y);
-      const uint8_t fl = is_inf ? 0xC0u : (uint8_t)(0x80u | (fe_greater<L>(y, yn) ? 0x20u : 0u));
-      o[0] = (uint8_t)((is_inf ? 0u : p[0]) | fl);
-#pragma unroll 4
-      for (int k = 1; k < FB; ++k) o[k] = is_inf ? 0u : p[k];
+  __shared__ __align__(16) uint8_t s_in[WG * PB];
+  __shared__ __align__(16) uint8_t s_out[WG * EB];
+  for (size_t base = (size_t)blockIdx.x * WG; base < n; base += (size_t)gridDim.x * WG) {
+    const size_t cnt = n - base < (size_t)WG ? n - base : (size_t)WG;
+    stage_copy(s_in, xy + base * PB, cnt * PB);
+    __syncthreads();
+    if (threadIdx.x < cnt) {
+      const uint8_t* p = s_in + threadIdx.x * PB;
+      uint8_t* o = s_out + threadIdx.x * EB;
+      const bool is_inf = inf != nullptr && inf[base + threadIdx.x] != 0;
+      if constexpr (FORMAT == FORMAT_SEC1) {
+        o[0] = is_inf ? 0u : (uint8_t)(2u | (p[PB - 1] & 1u));
+#pragma unroll
+        for (int k = 0; k < FB; ++k) o[1 + k] = is_inf ? 0u : p[k];
+      } else if constexpr (FORMAT == FORMAT_ZCASH) {
+        Fe<L> y, yn;
+        fe_load_be<CS>(y, p + FB);
+        fe_neg_canonical<CS>(yn, y);
+        const uint8_t fl = is_inf ? 0xC0u : (uint8_t)(0x80u | (fe_greater<L>(y, yn) ? 0x20u : 0u));
+        o[0] = (uint8_t)((is_inf ? 0u : p[0]) | fl);
+#pragma unroll
+        for (int k = 1; k < FB; ++k) o[k] = is_inf ? 0u : p[k];
+      } else {
+        // y little-endian with the low bit of x in bit 255 (encode_point, ed25519.rs:27-36); the
+        // identity is the ordinary point (0, 1), so there is no infinity record
+        static_assert(FB % 4 == 0, "word copies");
+        const uint32_t* pw = reinterpret_cast<const uint32_t*>(p);
+        uint32_t* ow = reinterpret_cast<uint32_t*>(o);
+#pragma unroll
+        for (int k = 0; k < FB / 4; ++k) ow[k] = pw[FB / 4 + k] | (k == FB / 4 - 1 ? (pw[0] & 1u) << 31 : 0u);
+      }
     }
+    __syncthreads();
+    stage_copy(out + base * EB, s_out, cnt * EB);
+    __syncthreads();
   }
 }
 
@@ -276,19 +308,6 @@ __global__ void __launch_bounds__(WG) k_ed_point_decompress(size_t n, const uint
     fe_store_le<CS>(out + i * 64, x);
     fe_store_le<CS>(out + i * 64 + 32, ry);
     flags[i] = status;
-  }
-}
-
-// x||y little-endian -> y with the low bit of x in bit 255 (encode_point, ed25519.rs:27-36)
-template <class CS>
-__global__ void __launch_bounds__(WG) k_ed_point_compress(size_t n, const uint8_t* __restrict__ xy, uint8_t* __restrict__ out) {
-  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n; i += (size_t)gridDim.x * WG) {
-    constexpr int FB = CS::FB;
-    const uint8_t* __restrict__ p = xy + i * (size_t)(2 * FB);
-    uint8_t* __restrict__ o = out + i * (size_t)FB;
-#pragma unroll 4
-    for (int k = 0; k < FB - 1; ++k) o[k] = p[FB + k];
-    o[FB - 1] = (uint8_t)(p[2 * FB - 1] | ((p[0] & 1u) << 7));
   }
 }
 
