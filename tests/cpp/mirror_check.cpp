@@ -59,6 +59,20 @@ int main() {
       }
       if (!none.is_infinity(i)) { std::printf("FAIL: k*G - k*G is not infinity at %zu\n", i); return 1; }
     }
+    // compress / decompress: SEC1 records round-trip, the infinity record included, and the
+    // generator's encoding is 0x03 || Gx (Gy is odd)
+    auto enc = a.compress(eng);
+    if (enc.size() != n * 33) { std::puts("FAIL: compressed size"); return 1; }
+    if (enc[0] != 0 || enc[33] != 0x03 || std::memcmp(&enc[34], GX, 32)) { std::puts("FAIL: SEC1 encoding of infinity / G"); return 1; }
+    auto back = eccx::PointsAffine<C>::decompress(eng, enc.data(), n);
+    for (size_t i = 0; i < n; ++i) {
+      if (back.is_infinity(i) != a.is_infinity(i) || back.is_rejected(i) || std::memcmp(back.x(i), a.x(i), 64)) {
+        std::printf("FAIL: decompress(compress(P)) != P at %zu\n", i);
+        return 1;
+      }
+    }
+    enc[33] = 0x05;  // not a SEC1 compressed prefix
+    if (!eccx::PointsAffine<C>::decompress(eng, enc.data(), n).is_rejected(1)) { std::puts("FAIL: bad prefix accepted"); return 1; }
     std::puts("mirror_check ok");
     return 0;
   } catch (const std::exception& e) {
