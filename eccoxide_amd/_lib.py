@@ -27,6 +27,7 @@ SYMBOLS = {
     "eccx_scalarmul_var_dev": (c_int, [c_void_p, c_int, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p]),
     "eccx_scalarmul_base_dev": (c_int, [c_void_p, c_int, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p]),
     "eccx_point_add": (c_int, [c_void_p, c_int, c_size_t, _u8p, _u8p, _u8p, _u8p, _u8p, _u8p, c_uint32]),
+    "eccx_point_add_dev": (c_int, [c_void_p, c_int, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p]),
     "eccx_double_scalarmul": (c_int, [c_void_p, c_int, c_size_t, _u8p, _u8p, _u8p, _u8p, _u8p, c_uint32]),
     "eccx_x25519": (c_int, [c_void_p, c_size_t, _u8p, _u8p, _u8p, _u8p, c_uint32]),
     "eccx_compressed_bytes": (c_int, [c_int]),

@@ -583,6 +583,25 @@ int eccx_scalarmul_base(eccx_ctx* ctx, int curve, size_t n, const uint8_t* scala
   return run_host(ctx, curve, true, n, scalars, nullptr, out, flags, proj, opts);
 }
 
+int eccx_point_add_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_a, const void* d_a_inf, const void* d_b,
+                       const void* d_b_inf, void* d_out, void* d_flags, uint32_t opts, void* stream) {
+  const CurveOps* ops = ops_of(curve);
+  if (!ctx) return ECCX_ERR_ARG;
+  if (!ops) return ECCX_ERR_CURVE;
+  if (n == 0) return ECCX_OK;
+  if (!d_a || !d_b || !d_out || !d_flags) return ECCX_ERR_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc = ensure_rows(ctx, ops, n);
+  if (rc) return rc;
+  HIP_TRY(ctx, ops->point_add(flat_grid(ctx, n), s, n, static_cast<const uint8_t*>(d_a), static_cast<const uint8_t*>(d_a_inf),
+                              static_cast<const uint8_t*>(d_b), static_cast<const uint8_t*>(d_b_inf), ctx->jac,
+                              static_cast<uint8_t*>(d_flags), (opts & ECCX_SUBTRACT) ? (1u << 5) : 0u));
+  HIP_TRY(ctx, ops->to_affine_hom(norm_grid(ctx, n), s, n, ctx->jac, static_cast<uint8_t*>(d_out),
+                                  static_cast<uint8_t*>(d_flags)));
+  return ECCX_OK;
+}
+
 int eccx_point_add(eccx_ctx* ctx, int curve, size_t n, const uint8_t* a, const uint8_t* a_inf, const uint8_t* b,
                    const uint8_t* b_inf, uint8_t* out, uint8_t* flags, uint32_t opts) {
   const CurveOps* ops = ops_of(curve);
@@ -592,37 +611,23 @@ int eccx_point_add(eccx_ctx* ctx, int curve, size_t n, const uint8_t* a, const u
   if (!a || !b || !out || !flags) return ECCX_ERR_ARG;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const size_t pb = 2 * (size_t)ops->info.fb;
-  uint8_t* d[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // a, b, a_inf, b_inf, out, flags
-  auto cleanup = [&]() {
-    for (auto p : d)
-      if (p) (void)hipFree(p);
-  };
-  auto fail = [&](hipError_t e, const char* what) {
-    ctx->err = std::string(what) + ": " + hipGetErrorString(e);
-    cleanup();
-    return e == hipErrorOutOfMemory ? ECCX_ERR_NOMEM : ECCX_ERR_HIP;
-  };
-  const size_t sizes[6] = {n * pb, n * pb, a_inf ? n : 0, b_inf ? n : 0, n * pb, n};
-  const uint8_t* src[4] = {a, b, a_inf, b_inf};
-  hipError_t e;
-  for (int i = 0; i < 6; ++i)
-    if (sizes[i] && (e = hipMalloc(&d[i], sizes[i])) != hipSuccess) return fail(e, "hipMalloc");
-  for (int i = 0; i < 4; ++i)
-    if (sizes[i] && (e = hipMemcpyAsync(d[i], src[i], sizes[i], hipMemcpyHostToDevice, ctx->stream)) != hipSuccess)
-      return fail(e, "hipMemcpyAsync");
-  int rc = ensure_rows(ctx, ops, n);
-  if (rc) { cleanup(); return rc; }
-  size_t need = (n + eccx::LAUNCH_WG - 1) / eccx::LAUNCH_WG;
-  int grid = (int)std::max<size_t>(1, std::min(need, (size_t)ctx->cus * 8));
-  if ((e = ops->point_add(grid, ctx->stream, n, d[0], d[2], d[1], d[3], ctx->jac, d[5],
-                          (opts & ECCX_SUBTRACT) ? (1u << 5) : 0u)) != hipSuccess)
-    return fail(e, "point_add launch");
-  if ((e = ops->to_affine_hom(norm_grid(ctx, n), ctx->stream, n, ctx->jac, d[4], d[5])) != hipSuccess)
-    return fail(e, "to_affine launch");
-  if ((e = hipMemcpyAsync(out, d[4], n * pb, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) return fail(e, "hipMemcpyAsync");
-  if ((e = hipMemcpyAsync(flags, d[5], n, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) return fail(e, "hipMemcpyAsync");
-  if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(e, "hipStreamSynchronize");
-  cleanup();
+  DevMem mem;
+  uint8_t *d_a = nullptr, *d_b = nullptr, *d_ai = nullptr, *d_bi = nullptr, *d_out = nullptr, *d_flags = nullptr;
+  HIP_TRY(ctx, mem.alloc(&d_a, n * pb));
+  HIP_TRY(ctx, mem.alloc(&d_b, n * pb));
+  if (a_inf) HIP_TRY(ctx, mem.alloc(&d_ai, n));
+  if (b_inf) HIP_TRY(ctx, mem.alloc(&d_bi, n));
+  HIP_TRY(ctx, mem.alloc(&d_out, n * pb));
+  HIP_TRY(ctx, mem.alloc(&d_flags, n));
+  HIP_TRY(ctx, hipMemcpyAsync(d_a, a, n * pb, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(d_b, b, n * pb, hipMemcpyHostToDevice, ctx->stream));
+  if (a_inf) HIP_TRY(ctx, hipMemcpyAsync(d_ai, a_inf, n, hipMemcpyHostToDevice, ctx->stream));
+  if (b_inf) HIP_TRY(ctx, hipMemcpyAsync(d_bi, b_inf, n, hipMemcpyHostToDevice, ctx->stream));
+  int rc = eccx_point_add_dev(ctx, curve, n, d_a, d_ai, d_b, d_bi, d_out, d_flags, opts, ctx->stream);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(out, d_out, n * pb, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(flags, d_flags, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return ECCX_OK;
 }
 

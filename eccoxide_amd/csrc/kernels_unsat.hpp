@@ -1212,10 +1212,11 @@ __global__ void __launch_bounds__(WG) k_batch_to_affine_unsat(size_t n, const ui
     T one;
 #pragma unroll
     for (int i = 0; i < CU::N; ++i) one.v[i] = CU::ONE[i];
-    auto z_present = [&](const T& z) {
-      if constexpr (MODE == NORM_MONTGOMERY_U) return !u_is_zero_mod_p(u_reduce(z));  // any multiple of p
-      else return !u_limbs_all_zero(z);
-    };
+    // Z = 0 means any multiple of p: the kernels encode infinity as all-zero limbs, but a unit
+    // fed a point that is not on the curve (rejected under ECCX_VALIDATE_POINTS, or garbage
+    // without it) can arrive with Z = p or 2p -- e.g. an Edwards "point" with x = +-y doubles to
+    // Z = 0 -- and must not zero the shared inverse of the units normalised beside it
+    auto z_present = [&](const T& z) { return !u_is_zero_mod_p(u_reduce(z)); };
     T pre[UN];  // prefix products of the (substituted) Z values
 #pragma unroll
     for (int u = 0; u < UN; ++u) {

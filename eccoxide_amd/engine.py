@@ -242,6 +242,31 @@ class Engine:
         self._check(rc)
         return out.raw[: n * 32], flags.raw[:n]
 
+    def point_add_t(self, curve, a, b, out=None, flags=None, *, a_inf=None, b_inf=None, subtract: bool = False,
+                    stream: Optional[int] = None):
+        """Device-tensor form of point_add (torch.uint8 CUDA tensors): out[i] = a[i] +- b[i]."""
+        import torch
+
+        cid = curve_id(curve)
+        fb = field_bytes(cid)
+        n = a.numel() // (2 * fb)
+        if out is None:
+            out = torch.empty((n, 2 * fb), dtype=torch.uint8, device=a.device)
+        if flags is None:
+            flags = torch.empty((n,), dtype=torch.uint8, device=a.device)
+        for t in (a, b, out, flags) + tuple(x for x in (a_inf, b_inf) if x is not None):
+            if not (t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()):
+                raise ValueError("tensors must be contiguous torch.uint8 CUDA tensors")
+        if a.numel() != n * 2 * fb or b.numel() != n * 2 * fb or any(x is not None and x.numel() != n for x in (a_inf, b_inf)):
+            raise ValueError("a, b and the infinity flags must describe the same number of units")
+        if stream is None:
+            stream = torch.cuda.current_stream(a.device).cuda_stream
+        rc = self._lib.eccx_point_add_dev(self._ctx, cid, n, a.data_ptr(), a_inf.data_ptr() if a_inf is not None else None,
+                                          b.data_ptr(), b_inf.data_ptr() if b_inf is not None else None,
+                                          out.data_ptr(), flags.data_ptr(), SUBTRACT if subtract else 0, stream)
+        self._check(rc)
+        return out, flags
+
     def double_scalarmul_t(self, curve, u1, u2, q, out=None, flags=None, *, subtract: bool = False,
                            validate: bool = False, stream: Optional[int] = None):
         """Device-tensor form of double_scalarmul (torch.uint8 CUDA tensors): out[i] = u1[i]*G +- u2[i]*q[i]."""

@@ -137,6 +137,9 @@ int eccx_scalarmul_base_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_sc
  *   out, flags  : as for eccx_scalarmul_var */
 int eccx_point_add(eccx_ctx* ctx, int curve, size_t n, const uint8_t* a, const uint8_t* a_inf, const uint8_t* b,
                    const uint8_t* b_inf, uint8_t* out, uint8_t* flags, uint32_t opts);
+/* Device-buffer form (d_a_inf / d_b_inf may be NULL), enqueued on `stream` without synchronising. */
+int eccx_point_add_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_a, const void* d_a_inf, const void* d_b,
+                       const void* d_b_inf, void* d_out, void* d_flags, uint32_t opts, void* stream);
 
 /* Double-scalar "verify shape": out[i] = u1[i]*G + u2[i]*Q[i]  (u1*G - u2*Q with ECCX_SUBTRACT).
  * The batched form of ECDSA verification's u1*G + u2*Q (src/protocol/ecdsa.rs:215) and of

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 from eccoxide_amd import workload as W
+from oracle import ecc_ref as R
 from tests.oracle_lib import golden
 
 pytestmark = pytest.mark.gpu
@@ -359,6 +360,47 @@ def test_point_validation(engine, oracle, curve):
             assert flags[i] == 2 and out[i * 2 * fb:(i + 1) * 2 * fb] == bytes(2 * fb)
         else:
             assert flags[i] == want_inf[i] and out[i * 2 * fb:(i + 1) * 2 * fb] == want_out[i * 2 * fb:(i + 1) * 2 * fb]
+
+
+@pytest.mark.parametrize("curve", ALL)
+@pytest.mark.parametrize("validate", [True, False])
+def test_bad_points_do_not_disturb_units_normalised_beside_them(engine, oracle, curve, validate):
+    """The batched normalisation shares one inversion between the 16 (8) units of a lane, 256
+    units apart.  A unit fed something that is not a curve point can reach Z = 0 (mod p) with
+    non-zero limbs -- an Edwards record with x = +-y doubles to Z = 0, a Weierstrass record with
+    y = p doubles to Z = 2*p*Z' -- and must neither be read as a finite point nor zero the
+    inverse of its neighbours: every well-formed unit still equals the oracle, with and without
+    ECCX_VALIDATE_POINTS (found by tools/soak.py, seed 777)."""
+    fb, sb = sizes(curve)
+    n = 4096 + 300
+    ks = W.random_scalars(curve, n, seed=91).tobytes()
+    good = bases(oracle, curve, n, seed=92)
+    pts = bytearray(good)
+    p = R.CURVES[curve].p
+    order = "little" if curve == "ed25519" else "big"
+    pb = 2 * fb
+    patterns = [b"\xff" * pb,                                             # x = y (mod p) / not canonical
+                good[:fb] + p.to_bytes(fb, order),                          # y = p: zero with non-zero digits
+                bytes(pb),                                                  # (0, 0)
+                (7).to_bytes(fb, order) + (7).to_bytes(fb, order),          # x = y, canonical
+                (7).to_bytes(fb, order) + (p - 7).to_bytes(fb, order)]      # x = -y
+    bad = list(range(3, n, 37))
+    for j, i in enumerate(bad):
+        pts[i * pb:(i + 1) * pb] = patterns[j % len(patterns)]
+    out, flags = engine.scalarmul_var(curve, ks, bytes(pts), validate=validate)
+    want_out, want_inf, _ = oracle.var(curve, ks, good)
+    isbad = set(bad)
+    for i in range(n):
+        if i in isbad:
+            if validate:
+                assert flags[i] == 2 and out[i * pb:(i + 1) * pb] == bytes(pb), i
+        else:
+            assert flags[i] == want_inf[i] and out[i * pb:(i + 1) * pb] == want_out[i * pb:(i + 1) * pb], i
+    if validate:
+        assert (out, flags) == engine.scalarmul_var(curve, ks, bytes(pts), validate=True, mirror=True)
+        # the fused double-scalar kernel shares the normalisation
+        d_out, d_flags = engine.double_scalarmul(curve, bytes(len(ks)), ks, bytes(pts), validate=True)
+        assert (d_out, d_flags) == (out, flags)
 
 
 # ---- reference properties at test sizes (src/tests/completeness.rs:60-117) -------------------

@@ -82,3 +82,32 @@ def test_point_add_ed25519(engine, oracle):
             want = R.ed_affine_add(c, P, Q)
             assert out[i * 64:(i + 1) * 64] == want[0].to_bytes(32, "little") + want[1].to_bytes(32, "little")
             assert flags[i] == (1 if want == (0, 1) else 0)
+
+
+@pytest.mark.parametrize("curve", ["p256r1", "bls12_381_g1", "ed25519"])
+def test_point_add_device_tensors(engine, oracle, curve):
+    """eccx_point_add_dev on torch tensors (with and without infinity flags, both signs), on the
+    caller's stream, against the host-buffer form."""
+    import torch
+
+    n = 1500
+    fb = oracle.fb(curve)
+    A = oracle.base(curve, W.random_scalars(curve, n, seed=61).tobytes())[0]
+    B = bytearray(oracle.base(curve, W.random_scalars(curve, n, seed=62).tobytes())[0])
+    B[:2 * fb * 10] = A[:2 * fb * 10]          # doublings (cancellations under subtract)
+    B = bytes(B)
+    a_inf = bytes(1 if i % 97 == 5 else 0 for i in range(n))
+    b_inf = bytes(1 if i % 89 == 7 else 0 for i in range(n))
+    dev = torch.device("cuda", 0)
+    t = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    stream = torch.cuda.Stream(dev)
+    for subtract in (False, True):
+        for with_inf in ((False, True) if curve != "ed25519" else (False,)):
+            want = engine.point_add(curve, A, B, a_inf=a_inf if with_inf else None, b_inf=b_inf if with_inf else None,
+                                    subtract=subtract)
+            with torch.cuda.stream(stream):
+                out, flags = engine.point_add_t(curve, t(A).reshape(n, -1), t(B).reshape(n, -1),
+                                                a_inf=t(a_inf) if with_inf else None, b_inf=t(b_inf) if with_inf else None,
+                                                subtract=subtract, stream=stream.cuda_stream)
+            stream.synchronize()
+            assert out.cpu().numpy().tobytes() == want[0] and flags.cpu().numpy().tobytes() == want[1], (subtract, with_inf)

@@ -85,6 +85,38 @@ def main():
             s_out, s_fl = eng.point_add(curve, b_mir.cpu().numpy().tobytes(), v_mir.cpu().numpy().tobytes(),
                                         a_inf=a_inf, b_inf=b_inf, subtract=subtract)
             assert d_out.cpu().numpy().tobytes() == s_out and d_fl.cpu().numpy().tobytes() == s_fl, ("dsm", curve, n, subtract, rounds)
+        # wire formats: compress -> decompress gives the points back; the other sign gives the
+        # negated point (their sum is the neutral element), except where the flipped encoding is
+        # not canonical (edwards25519 x = 0) and must be rejected
+        ed = curve == "ed25519"
+        enc = eng.point_compress_t(curve, v_def, None if ed else vf_def)
+        back, bfl = eng.point_decompress_t(curve, enc)
+        assert torch.equal(back, v_def) and torch.equal(bfl, torch.zeros_like(vf_def) if ed else vf_def), ("codec", curve, n, rounds)
+        flip = enc.clone()
+        if ed:
+            flip[:, 31] ^= 0x80
+        elif curve == "bls12_381_g1":
+            flip[:, 0] ^= 0x20
+        else:
+            flip[:, 0] ^= 0x01
+        neg, nfl = eng.point_decompress_t(curve, flip)
+        if os.environ.get("SOAK_DEBUG") and n <= 4:
+            print("debug", curve, n, "points", v_def.cpu().numpy().tobytes().hex(), "flags", vf_def.cpu().tolist(),
+                  "enc", enc.cpu().numpy().tobytes().hex(), "flip flags", nfl.cpu().tolist(), flush=True)
+        fb = E.field_bytes(curve)
+        if ed:
+            x_zero = ~(v_def[:, :fb] != 0).any(dim=1)
+            assert torch.equal(nfl == 2, x_zero) and not bool((nfl == 1).any()), ("codec flip", curve, n, rounds)
+            keep = (~x_zero).cpu()
+        else:
+            was_inf = vf_def != 0   # 0x00.. ^ 1 / 0xC0.. ^ 0x20 are not encodings
+            assert torch.equal(nfl == 2, was_inf) and not bool((nfl == 1).any()), ("codec flip", curve, n, rounds)
+            keep = (~was_inf).cpu()
+        if bool(keep.any()):
+            a_b = v_def.cpu()[keep].contiguous().numpy().tobytes()
+            n_b = neg.cpu()[keep].contiguous().numpy().tobytes()
+            _, zfl = eng.point_add(curve, a_b, n_b)
+            assert zfl == b"\x01" * int(keep.sum()), ("codec negation", curve, n, rounds)
         # validation: corrupt some bases (off-curve / non-canonical) and require identical rejection
         # (flag 2, zero bytes) from both stacks and from the fused kernel
         if rounds % 4 == 0:
@@ -95,6 +127,12 @@ def main():
                 bad[sel & (torch.rand(n, device=dev) < 0.3)] = 0xFF   # non-canonical coordinates
             o1, f1 = eng.scalarmul_var_t(curve, k2, bad, validate=True)
             o2, f2 = eng.scalarmul_var_t(curve, k2, bad, validate=True, mirror=True)
+            if not (torch.equal(o1, o2) and torch.equal(f1, f2)):
+                diff = ((o1 != o2).any(dim=1) | (f1 != f2)).nonzero().flatten().cpu().tolist()
+                for i in diff[:4]:
+                    print("validate mismatch", curve, "unit", i, "scalar", k2[i].cpu().numpy().tobytes().hex(),
+                          "base", bad[i].cpu().numpy().tobytes().hex(), "default", o1[i].cpu().numpy().tobytes().hex(), int(f1[i]),
+                          "mirror", o2[i].cpu().numpy().tobytes().hex(), int(f2[i]), flush=True)
             assert torch.equal(o1, o2) and torch.equal(f1, f2), ("validate", curve, n, rounds)
             o3, f3 = eng.double_scalarmul_t(curve, torch.zeros_like(k1), k2, bad, validate=True)
             rej = f1 == 2
