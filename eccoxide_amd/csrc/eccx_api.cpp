@@ -649,7 +649,12 @@ int eccx_point_decompress_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_
   hipStream_t s = static_cast<hipStream_t>(stream);
   uint8_t* out = static_cast<uint8_t*>(d_out);
   uint8_t* flags = static_cast<uint8_t*>(d_flags);
-  HIP_TRY(ctx, ops->decompress(flat_grid(ctx, n), s, n, static_cast<const uint8_t*>(d_enc), out, flags));
+  if (opts & ECCX_UNCOMPRESSED) {
+    if (!ops->decompress_raw) return ECCX_ERR_ARG;  // the flavour exists for bls12_381_g1 only
+    HIP_TRY(ctx, ops->decompress_raw(flat_grid(ctx, n), s, n, static_cast<const uint8_t*>(d_enc), out, flags));
+  } else {
+    HIP_TRY(ctx, ops->decompress(flat_grid(ctx, n), s, n, static_cast<const uint8_t*>(d_enc), out, flags));
+  }
   if ((opts & ECCX_CHECK_SUBGROUP) && curve == ECCX_BLS12_381_G1) {
     // [r]P through the variable-base kernel; rejected records hold (0, 0), whose multiple is
     // some garbage the merge ignores
@@ -681,10 +686,11 @@ int eccx_point_compress_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_xy
   if (!ops) return ECCX_ERR_CURVE;
   if (n == 0) return ECCX_OK;
   if (!d_xy || !d_out) return ECCX_ERR_ARG;
-  (void)opts;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, ops->compress(flat_grid(ctx, n), static_cast<hipStream_t>(stream), n, static_cast<const uint8_t*>(d_xy),
-                             static_cast<const uint8_t*>(d_inf), static_cast<uint8_t*>(d_out)));
+  if ((opts & ECCX_UNCOMPRESSED) && !ops->compress_raw) return ECCX_ERR_ARG;
+  HIP_TRY(ctx, ((opts & ECCX_UNCOMPRESSED) ? ops->compress_raw : ops->compress)(
+                   flat_grid(ctx, n), static_cast<hipStream_t>(stream), n, static_cast<const uint8_t*>(d_xy),
+                   static_cast<const uint8_t*>(d_inf), static_cast<uint8_t*>(d_out)));
   return ECCX_OK;
 }
 
@@ -696,7 +702,7 @@ int eccx_point_decompress(eccx_ctx* ctx, int curve, size_t n, const uint8_t* enc
   if (n == 0) return ECCX_OK;
   if (!enc || !out || !flags) return ECCX_ERR_ARG;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  const size_t eb = (size_t)ops->enc_bytes, pb = 2 * (size_t)ops->info.fb;
+  const size_t pb = 2 * (size_t)ops->info.fb, eb = (opts & ECCX_UNCOMPRESSED) ? pb : (size_t)ops->enc_bytes;
   DevMem mem;
   uint8_t *d_enc = nullptr, *d_out = nullptr, *d_flags = nullptr;
   HIP_TRY(ctx, mem.alloc(&d_enc, n * eb));
@@ -719,7 +725,7 @@ int eccx_point_compress(eccx_ctx* ctx, int curve, size_t n, const uint8_t* xy, c
   if (n == 0) return ECCX_OK;
   if (!xy || !out) return ECCX_ERR_ARG;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  const size_t eb = (size_t)ops->enc_bytes, pb = 2 * (size_t)ops->info.fb;
+  const size_t pb = 2 * (size_t)ops->info.fb, eb = (opts & ECCX_UNCOMPRESSED) ? pb : (size_t)ops->enc_bytes;
   DevMem mem;
   uint8_t *d_xy = nullptr, *d_inf = nullptr, *d_out = nullptr;
   HIP_TRY(ctx, mem.alloc(&d_xy, n * pb));

@@ -94,7 +94,7 @@ hipError_t launch_x25519_to_u(int grid, hipStream_t s, size_t n, const uint32_t*
 }
 const CurveOps& ops_ED25519() {
   static const CurveOps o = {{ED25519::FB, ED25519::SB, ED25519::L, 4 * ED25519::L, 0, 1, ED_VAR_ROW_WORDS,
-                              (urow3_words<ED25519U>() > row_words<ED25519::L>() ? urow3_words<ED25519U>() : row_words<ED25519::L>())}, var_, base_, var_fast_, base_lds_, to_affine_hom_, var_grid_, var_fast_grid_, to_affine_var_, point_add_, ED_U_ENTRY_WORDS, comb_bits<ED25519U>(), comb_convert_, base_w8_, ED_LDS_BITS, ED_LDS_WINDOWS, ED_LDS_DIGITS, ED_LDS_ENTRY_WORDS, lds_convert_, var_fused_, 32, decompress_, compress_};
+                              (urow3_words<ED25519U>() > row_words<ED25519::L>() ? urow3_words<ED25519U>() : row_words<ED25519::L>())}, var_, base_, var_fast_, base_lds_, to_affine_hom_, var_grid_, var_fast_grid_, to_affine_var_, point_add_, ED_U_ENTRY_WORDS, comb_bits<ED25519U>(), comb_convert_, base_w8_, ED_LDS_BITS, ED_LDS_WINDOWS, ED_LDS_DIGITS, ED_LDS_ENTRY_WORDS, lds_convert_, var_fused_, 32, decompress_, compress_, nullptr, nullptr};
   return o;
 }
 }  // namespace eccx

@@ -27,7 +27,7 @@
 namespace eccx {
 
 enum : uint8_t { CODEC_OK = 0, CODEC_INFINITY = 1, CODEC_INVALID = 2 };
-enum : int { FORMAT_SEC1 = 0, FORMAT_ZCASH = 1, FORMAT_RFC8032 = 2 };
+enum : int { FORMAT_SEC1 = 0, FORMAT_ZCASH = 1, FORMAT_RFC8032 = 2, FORMAT_ZCASH_RAW = 3 };
 
 template <class CU>
 using UT = U<CU, 1, 3>;
@@ -141,8 +141,19 @@ ECCX_DEV bool fe_all_zero(const Fe<L>& a) {
   return any == 0;
 }
 
+// x^3 + a x + b for a = -3 or a = 0 (working form)
+template <class CU>
+ECCX_DEV UT<CU> ut_curve_rhs(const UT<CU>& x) {
+  UT<CU> cb;
+#pragma unroll
+  for (int k = 0; k < CU::N; ++k) cb.v[k] = CU::CB[k];
+  const UT<CU> x3 = ut_mul(u_sqr(x), x);
+  if constexpr (CU::Sat::A0) return u_fit<1, 3>(u_reduce(u_add(x3, cb)));
+  else return u_fit<1, 3>(u_reduce(u_add(u_sub(x3, u_add(u_add(x, x), x)), cb)));
+}
+
 template <class CS, int FORMAT>
-constexpr int enc_bytes() { return FORMAT == FORMAT_SEC1 ? CS::FB + 1 : CS::FB; }
+constexpr int enc_bytes() { return FORMAT == FORMAT_SEC1 ? CS::FB + 1 : (FORMAT == FORMAT_ZCASH_RAW ? 2 * CS::FB : CS::FB); }
 
 // enc -> x||y (big-endian), flags: 0 point, 1 infinity encoding, 2 rejected (bad prefix or
 // flag bits, x not below p, x^3 + a x + b not a square).  Rejected and infinity records leave
@@ -178,13 +189,7 @@ __global__ void __launch_bounds__(WG) k_point_decompress(size_t n, const uint8_t
     if (status == CODEC_OK && !fe_is_canonical<CS>(rx)) status = CODEC_INVALID;
     // the arithmetic runs on every lane (a rejected x is some integer below 2^(8 FB))
     const UT<CU> x = u_as<1, 3>(u_to_mont<CU>(rx));
-    UT<CU> cb;
-#pragma unroll
-    for (int k = 0; k < CU::N; ++k) cb.v[k] = CU::CB[k];
-    const UT<CU> x3 = ut_mul(u_sqr(x), x);
-    UT<CU> rhs;
-    if constexpr (CS::A0) rhs = u_fit<1, 3>(u_reduce(u_add(x3, cb)));
-    else rhs = u_fit<1, 3>(u_reduce(u_add(u_sub(x3, u_add(u_add(x, x), x)), cb)));
+    const UT<CU> rhs = ut_curve_rhs<CU>(x);
     const UT<CU> r = ut_root_pow<CU>(rhs);
     if (status == CODEC_OK && !ut_equal(u_sqr(r), rhs)) status = CODEC_INVALID;
     Fe<L> y, yn;
@@ -248,6 +253,12 @@ __global__ void __launch_bounds__(WG) k_point_compress(size_t n, const uint8_t* 
         o[0] = (uint8_t)((is_inf ? 0u : p[0]) | fl);
 #pragma unroll
         for (int k = 1; k < FB; ++k) o[k] = is_inf ? 0u : p[k];
+      } else if constexpr (FORMAT == FORMAT_ZCASH_RAW) {
+        // to_uncompressed (serialize.rs:269-277): x||y as they stand, all flags clear; the identity
+        // is the infinity flag alone (:98-100)
+        o[0] = is_inf ? 0x40u : p[0];
+#pragma unroll
+        for (int k = 1; k < PB; ++k) o[k] = is_inf ? 0u : p[k];
       } else {
         // y little-endian with the low bit of x in bit 255 (encode_point, ed25519.rs:27-36); the
         // identity is the ordinary point (0, 1), so there is no infinity record
@@ -261,6 +272,41 @@ __global__ void __launch_bounds__(WG) k_point_compress(size_t n, const uint8_t* 
     __syncthreads();
     stage_copy(out + base * EB, s_out, cnt * EB);
     __syncthreads();
+  }
+}
+
+// zcash uncompressed flavour -> x||y (from_uncompressed_oncurve_only, serialize.rs:371-383:
+// read_uncompressed_flags :129-141, read_uncompressed_affine :207-224): the compression and sort
+// bits must be clear, bit 6 marks the identity (all else zero), both coordinates below p and on
+// the curve.  Flags as for k_point_decompress.
+template <class CU>
+__global__ void __launch_bounds__(WG) k_point_from_uncompressed(size_t n, const uint8_t* __restrict__ enc, uint8_t* __restrict__ out,
+                                                                uint8_t* __restrict__ flags) {
+  using CS = typename CU::Sat;
+  constexpr int L = CS::L;
+  constexpr int FB = CS::FB;
+  static_assert(8 * FB - CS::PBITS >= 3, "the three flag bits need room above the field");
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n; i += (size_t)gridDim.x * WG) {
+    const uint8_t* __restrict__ e = enc + i * (size_t)(2 * FB);
+    const uint32_t b0 = e[0];
+    Fe<L> rx, ry;
+    fe_load_be<CS>(rx, e);
+    fe_load_be<CS>(ry, e + FB);
+    rx.v[L - 1] &= ~(0xE0u << ((FB - 1) % 4 * 8));
+    uint8_t status = CODEC_OK;
+    if (b0 & 0xA0u) status = CODEC_INVALID;
+    else if (b0 & 0x40u) status = (fe_all_zero<L>(rx) && fe_all_zero<L>(ry)) ? CODEC_INFINITY : CODEC_INVALID;
+    if (status == CODEC_OK && !(fe_is_canonical<CS>(rx) && fe_is_canonical<CS>(ry))) status = CODEC_INVALID;
+    const UT<CU> x = u_as<1, 3>(u_to_mont<CU>(rx));
+    const UT<CU> y = u_as<1, 3>(u_to_mont<CU>(ry));
+    if (status == CODEC_OK && !ut_equal(u_sqr(y), ut_curve_rhs<CU>(x))) status = CODEC_INVALID;
+    if (status != CODEC_OK) {
+#pragma unroll
+      for (int k = 0; k < L; ++k) { rx.v[k] = 0; ry.v[k] = 0; }
+    }
+    fe_store_be<CS>(out + i * (size_t)(2 * FB), rx);
+    fe_store_be<CS>(out + i * (size_t)(2 * FB) + FB, ry);
+    flags[i] = status;
   }
 }
 

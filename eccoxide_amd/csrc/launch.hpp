@@ -72,6 +72,9 @@ struct CurveOps {
   int enc_bytes;
   hipError_t (*decompress)(int grid, hipStream_t s, size_t n, const uint8_t* enc, uint8_t* out, uint8_t* flags);
   hipError_t (*compress)(int grid, hipStream_t s, size_t n, const uint8_t* xy, const uint8_t* inf, uint8_t* out);
+  // the zcash uncompressed flavour, 2 FB bytes per point (bls12_381_g1 only, else null)
+  hipError_t (*decompress_raw)(int grid, hipStream_t s, size_t n, const uint8_t* enc, uint8_t* out, uint8_t* flags);
+  hipError_t (*compress_raw)(int grid, hipStream_t s, size_t n, const uint8_t* xy, const uint8_t* inf, uint8_t* out);
 };
 // units normalised per lane with one inversion: 16 where the prefix products fit the register
 // file (8-limb fields), 8 above

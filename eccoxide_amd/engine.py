@@ -20,6 +20,7 @@ TABLE_IN_L2 = 1 << 3
 X25519_RAW_LADDER = 1 << 4
 SUBTRACT = 1 << 5
 CHECK_SUBGROUP = 1 << 6
+UNCOMPRESSED = 1 << 7
 FLAG_FINITE, FLAG_INFINITY, FLAG_REJECTED = 0, 1, 2
 
 
@@ -160,29 +161,33 @@ class Engine:
         """Bytes per compressed point: FB + 1 (SEC1), 48 (zcash G1), 32 (RFC 8032)."""
         return self._lib.eccx_compressed_bytes(curve_id(curve))
 
-    def point_decompress(self, curve, enc: bytes, *, check_subgroup: bool = False):
+    def point_decompress(self, curve, enc: bytes, *, check_subgroup: bool = False, uncompressed: bool = False):
         """Compressed encodings -> (n x 2FB affine x||y, flags): 0 point, 1 infinity encoding, 2 rejected.
         SEC1 for the sec2 curves, zcash for bls12_381_g1 (check_subgroup=True: from_compressed,
         else from_compressed_oncurve_only), RFC 8032 for ed25519."""
         cid = curve_id(curve)
-        fb, eb = field_bytes(cid), self.compressed_bytes(cid)
+        fb = field_bytes(cid)
+        eb = 2 * fb if uncompressed else self.compressed_bytes(cid)
         if len(enc) % eb:
             raise ValueError(f"enc must be n x {eb} bytes")
         n = len(enc) // eb
         out = ctypes.create_string_buffer(max(1, n * 2 * fb))
         flags = ctypes.create_string_buffer(max(1, n))
-        self._check(self._lib.eccx_point_decompress(self._ctx, cid, n, enc, out, flags, CHECK_SUBGROUP if check_subgroup else 0))
+        self._check(self._lib.eccx_point_decompress(self._ctx, cid, n, enc, out, flags,
+                                                    (CHECK_SUBGROUP if check_subgroup else 0) | (UNCOMPRESSED if uncompressed else 0)))
         return out.raw[: n * 2 * fb], flags.raw[:n]
 
-    def point_compress(self, curve, xy: bytes, inf: Optional[bytes] = None) -> bytes:
-        """Affine x||y records (+ optional infinity flags) -> compressed encodings."""
+    def point_compress(self, curve, xy: bytes, inf: Optional[bytes] = None, *, uncompressed: bool = False) -> bytes:
+        """Affine x||y records (+ optional infinity flags) -> compressed encodings (uncompressed=True:
+        the 96-byte zcash flavour of bls12_381_g1)."""
         cid = curve_id(curve)
-        fb, eb = field_bytes(cid), self.compressed_bytes(cid)
+        fb = field_bytes(cid)
+        eb = 2 * fb if uncompressed else self.compressed_bytes(cid)
         if len(xy) % (2 * fb) or (inf is not None and len(inf) != len(xy) // (2 * fb)):
             raise ValueError("xy must be n x 2FB bytes and inf n bytes")
         n = len(xy) // (2 * fb)
         out = ctypes.create_string_buffer(max(1, n * eb))
-        self._check(self._lib.eccx_point_compress(self._ctx, cid, n, xy, inf, out, 0))
+        self._check(self._lib.eccx_point_compress(self._ctx, cid, n, xy, inf, out, UNCOMPRESSED if uncompressed else 0))
         return out.raw[: n * eb]
 
     def point_decompress_t(self, curve, enc, out=None, flags=None, *, check_subgroup: bool = False,

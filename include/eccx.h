@@ -87,7 +87,8 @@ enum {
   ECCX_TABLE_IN_L2 = 1u << 3,    /* fixed base: the reference's 4-bit comb, table read through L1/L2 */
   ECCX_X25519_RAW_LADDER = 1u << 4, /* eccx_x25519: raw MontgomeryPoint::scale_bytes semantics */
   ECCX_SUBTRACT = 1u << 5,         /* eccx_point_add: compute a - b */
-  ECCX_CHECK_SUBGROUP = 1u << 6    /* eccx_point_decompress, bls12_381_g1: reject points outside G1 */
+  ECCX_CHECK_SUBGROUP = 1u << 6,   /* eccx_point_decompress, bls12_381_g1: reject points outside G1 */
+  ECCX_UNCOMPRESSED = 1u << 7      /* eccx_point_[de]compress, bls12_381_g1: the 96-byte zcash flavour */
 };
 
 /* flag values written per unit */
@@ -193,7 +194,13 @@ int eccx_x25519_dev(eccx_ctx* ctx, size_t n, const void* d_scalars, const void* 
  * eccx_point_compress: xy n x 2FB canonical coordinates, inf NULL or n bytes (non-zero = point
  *   at infinity, as the flags of the scalar multiplications report it) -> out n x
  *   eccx_compressed_bytes(curve).
- * The _dev forms take device memory and enqueue on `stream` without synchronising, so
+ * ECCX_UNCOMPRESSED (bls12_381_g1 only, ECCX_ERR_ARG elsewhere) selects the zcash uncompressed
+ *   flavour, 2FB = 96 bytes per point: x||y with the flag bits in the leading byte -- compression
+ *   and sort bits clear, bit 6 alone for the point at infinity (to_uncompressed /
+ *   from_uncompressed[_oncurve_only], serialize.rs:269-279,353-383); decoding checks both
+ *   coordinates are below p and satisfy the curve equation.
+ * The _dev forms take device memory and enqueue on `stream` without synchronising (except under
+ * ECCX_CHECK_SUBGROUP, whose temporaries are released after a stream synchronisation), so
  * decompress -> scalarmul -> compress chains stay on the GPU. */
 int eccx_compressed_bytes(int curve);
 int eccx_point_decompress(eccx_ctx* ctx, int curve, size_t n, const uint8_t* enc, uint8_t* out, uint8_t* flags,

@@ -683,3 +683,30 @@ def point_decompress_bytes(curve: str, enc: bytes, check_subgroup: bool = False)
         out += bytes(2 * fb) if P is None else P[0].to_bytes(fb, order) + P[1].to_bytes(fb, order)
         flags.append(st)
     return bytes(out), bytes(flags)
+
+
+def ref_g1_to_uncompressed(P: Affine) -> bytes:
+    """to_uncompressed (bls12_381/serialize.rs:269-277): x||y big-endian, flags clear; the identity
+    is the infinity flag alone (infinity_uncompressed, :98-100)."""
+    c = BLS12_381_G1
+    if P is None:
+        return bytes([0x40]) + bytes(2 * c.fb - 1)
+    return P[0].to_bytes(c.fb, "big") + P[1].to_bytes(c.fb, "big")
+
+
+def ref_g1_from_uncompressed(enc: bytes, check_subgroup: bool = False) -> Tuple[Affine, int]:
+    """from_uncompressed[_oncurve_only] (serialize.rs:353-383; read_uncompressed_flags :129-141,
+    read_uncompressed_affine :207-224)."""
+    c = BLS12_381_G1
+    fl = enc[0] & 0xE0
+    x = int.from_bytes(enc[:c.fb], "big") & ((1 << (8 * c.fb - 3)) - 1)
+    y = int.from_bytes(enc[c.fb:], "big")
+    if fl & 0xA0:
+        return None, CODEC_INVALID
+    if fl & 0x40:
+        return None, (CODEC_INFINITY if x == 0 and y == 0 else CODEC_INVALID)
+    if x >= c.p or y >= c.p or not on_curve(c, (x, y)):
+        return None, CODEC_INVALID
+    if check_subgroup and affine_mul(c, c.n, (x, y)) is not None:
+        return None, CODEC_INVALID
+    return (x, y), CODEC_OK

@@ -69,6 +69,16 @@ def test_oracle_codec_rejections():
     assert R.ref_point_decompress("ed25519", (1).to_bytes(32, "little")) == ((0, 1), 0)
 
 
+def test_oracle_uncompressed_flavour_matches_reference_encodings():
+    c = R.BLS12_381_G1
+    for e in golden("bls_g1.json")["uncompressed"]:
+        P = R.affine_mul(c, e["k"], (c.gx, c.gy))
+        assert R.ref_g1_to_uncompressed(P).hex() == e["bytes"]
+        assert R.ref_g1_from_uncompressed(bytes.fromhex(e["bytes"]), True) == (P, 0)
+    assert R.ref_g1_from_uncompressed(bytes([0x40]) + bytes(95)) == (None, 1)
+    assert R.ref_g1_from_uncompressed(bytes([0x40]) + bytes(94) + b"\x01")[1] == 2
+
+
 # ---- GPU ------------------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("curve", CURVES)
@@ -224,3 +234,76 @@ def test_codec_round_trip_at_full_batch(engine, curve):
     torch.cuda.synchronize()
     assert int(fl.sum()) == 0 and int(bfl.sum()) == 0
     assert torch.equal(back, pts)
+
+
+@pytest.mark.gpu
+def test_zcash_uncompressed_flavour(engine, oracle):
+    """to_uncompressed / from_uncompressed[_oncurve_only] (serialize.rs:269-279,353-383) against
+    the oracle: reference encodings, round trip with an infinity record, every flag pattern,
+    non-canonical and off-curve coordinates, a curve point outside G1."""
+    curve = "bls12_381_g1"
+    c = R.BLS12_381_G1
+    kats = golden("bls_g1.json")["uncompressed"]
+    enc = b"".join(bytes.fromhex(e["bytes"]) for e in kats)
+    out, flags = engine.point_decompress(curve, enc, uncompressed=True, check_subgroup=True)
+    assert flags == bytes(len(kats)) and out == enc
+    n = 600
+    xy = _points(oracle, curve, n, seed=17)
+    inf = bytearray(n); inf[4] = 1
+    raw = engine.point_compress(curve, xy, bytes(inf), uncompressed=True)
+    want = b"".join(R.ref_g1_to_uncompressed(None if inf[i] else (int.from_bytes(xy[96 * i:96 * i + 48], "big"),
+                                                                    int.from_bytes(xy[96 * i + 48:96 * i + 96], "big"))) for i in range(n))
+    assert raw == want
+    rnd = random.Random(99)
+    recs = [raw[96 * i:96 * i + 96] for i in range(40)]
+    g = raw[:96]
+    for pre in (0x20, 0x40, 0x60, 0x80, 0xA0, 0xC0, 0xE0):
+        recs.append(bytes([g[0] | pre]) + g[1:])
+        recs.append(bytes([pre]) + bytes(95))
+    recs.append(c.p.to_bytes(48, "big") + g[48:])                       # x = p
+    recs.append(g[:48] + c.p.to_bytes(48, "big"))                       # y = p
+    recs.append(g[:48] + (c.p - int.from_bytes(g[48:], "big")).to_bytes(48, "big"))   # -G
+    recs.append(g[:95] + bytes([g[95] ^ 1]))                            # off the curve
+    x = 1
+    while True:                                                          # a curve point outside G1
+        x += 1
+        P = R.ref_w_decompress_xy(c, x, False)
+        if P is not None:
+            recs.append(R.ref_g1_to_uncompressed(P))
+            break
+    for _ in range(100):
+        recs.append(bytes(rnd.getrandbits(8) for _ in range(96)))
+    blob = b"".join(recs)
+    for chk in (False, True):
+        out, flags = engine.point_decompress(curve, blob, uncompressed=True, check_subgroup=chk)
+        for i, r in enumerate(recs):
+            P, st = R.ref_g1_from_uncompressed(r, chk)
+            assert flags[i] == st, (i, chk)
+            assert out[96 * i:96 * i + 96] == (bytes(96) if P is None else P[0].to_bytes(48, "big") + P[1].to_bytes(48, "big")), (i, chk)
+    with pytest.raises(Exception):
+        engine.point_compress("p256r1", bytes(64), uncompressed=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curve", ["p256r1", "p521r1", "ed25519"])
+def test_codec_on_misaligned_device_buffers(engine, oracle, curve):
+    """Device buffers at odd byte offsets (tensor views): the 16-byte staging of the compress kernel
+    falls back to byte accesses; a ragged last workgroup on top."""
+    import torch
+
+    n = 256 * 3 + 41
+    fb, eb = oracle.fb(curve), R.compressed_bytes(curve)
+    xy = _points(oracle, curve, n, seed=23)
+    want = R.point_compress_bytes(curve, xy)
+    dev = torch.device("cuda", 0)
+    for off_in, off_out in ((1, 0), (0, 3), (5, 7), (16, 32)):
+        src = torch.zeros(n * 2 * fb + 64, dtype=torch.uint8, device=dev)
+        src[off_in:off_in + n * 2 * fb] = torch.frombuffer(bytearray(xy), dtype=torch.uint8).to(dev)
+        dst = torch.full((n * eb + 64,), 0xAA, dtype=torch.uint8, device=dev)
+        engine.point_compress_t(curve, src[off_in:off_in + n * 2 * fb], None, dst[off_out:off_out + n * eb])
+        torch.cuda.synchronize()
+        assert dst[off_out:off_out + n * eb].cpu().numpy().tobytes() == want
+        assert bool((dst[:off_out] == 0xAA).all()) and bool((dst[off_out + n * eb:] == 0xAA).all())   # nothing written outside
+        back, fl = engine.point_decompress_t(curve, dst[off_out:off_out + n * eb])
+        torch.cuda.synchronize()
+        assert back.cpu().numpy().tobytes() == xy and int(fl.sum()) == 0

@@ -387,15 +387,17 @@ def test_bad_points_do_not_disturb_units_normalised_beside_them(engine, oracle, 
     bad = list(range(3, n, 37))
     for j, i in enumerate(bad):
         pts[i * pb:(i + 1) * pb] = patterns[j % len(patterns)]
-    out, flags = engine.scalarmul_var(curve, ks, bytes(pts), validate=validate)
     want_out, want_inf, _ = oracle.var(curve, ks, good)
     isbad = set(bad)
-    for i in range(n):
-        if i in isbad:
-            if validate:
-                assert flags[i] == 2 and out[i * pb:(i + 1) * pb] == bytes(pb), i
-        else:
-            assert flags[i] == want_inf[i] and out[i * pb:(i + 1) * pb] == want_out[i * pb:(i + 1) * pb], i
+    for mirror in (False, True):
+        out, flags = engine.scalarmul_var(curve, ks, bytes(pts), validate=validate, mirror=mirror)
+        for i in range(n):
+            if i in isbad:
+                if validate:
+                    assert flags[i] == 2 and out[i * pb:(i + 1) * pb] == bytes(pb), (i, mirror)
+            else:
+                assert flags[i] == want_inf[i] and out[i * pb:(i + 1) * pb] == want_out[i * pb:(i + 1) * pb], (i, mirror)
+    out, flags = engine.scalarmul_var(curve, ks, bytes(pts), validate=validate)
     if validate:
         assert (out, flags) == engine.scalarmul_var(curve, ks, bytes(pts), validate=True, mirror=True)
         # the fused double-scalar kernel shares the normalisation
