@@ -105,14 +105,14 @@ WORKLOADS = {
 # read from inside this process, so the figure is the committed measurement of this very
 # workload, not a live one; null where no profile has been taken.
 MEASURED_TRAFFIC = {
-    "p256r1_var_2^20": {"bytes": 2 * (6802012096 + 109864632) + 3686706116 + 70264824,
-                        "fetch_raw": 6802012096 + 109864632, "write": 3686706116 + 70264824,
+    "p256r1_var_2^20": {"bytes": 2 * (6806181156 + 110009232) + 3673585499 + 70260848,
+                        "fetch_raw": 6806181156 + 110009232, "write": 3673585499 + 70260848,
                         "source": "profiles/r01_p256r1_var_u29.json"},
-    "ed25519_base_2^20": {"bytes": 2 * (1132189418 + 108917632) + 118712629 + 70274916,
-                          "fetch_raw": 1132189418 + 108917632, "write": 118712629 + 70274916,
+    "ed25519_base_2^20": {"bytes": 2 * (1133845141 + 108967085) + 118731472 + 70264914,
+                          "fetch_raw": 1133845141 + 108967085, "write": 118731472 + 70264914,
                           "source": "profiles/r01_ed25519_base.json"},
-    "x25519_2^20": {"bytes": 2 * (31777600 + 106718518) + 118492877 + 36700406,
-                    "fetch_raw": 31777600 + 106718518, "write": 118492877 + 36700406,
+    "x25519_2^20": {"bytes": 2 * (31295085 + 106660900) + 118496251 + 36701193,
+                    "fetch_raw": 31295085 + 106660900, "write": 118496251 + 36701193,
                     "source": "profiles/r01_x25519.json"},
 }
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec

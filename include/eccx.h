@@ -17,6 +17,14 @@
  *   output normalisation       Point::to_affine / to_affine_ct   curve_macros.rs:247-268,
  *                              projective.rs:655-682, curve25519.rs:663-666
  *   eccx_comb_table            COMB_TABLE constants              src/params/comb/<curve>.rs
+ *   eccx_point_add[_dev]       impl Add / Sub / Neg, CurveGroup::double   curve_macros.rs:297-411, group.rs:28-70
+ *   eccx_double_scalarmul[_dev]  u1*G + u2*Q                     src/protocol/ecdsa.rs:215, ed25519.rs:145
+ *   eccx_x25519[_dev]          MontgomeryPoint ladder / x25519   curve25519.rs:474-541, src/protocol/x25519.rs:14-51
+ *   eccx_point_compress[_dev]  PointAffine::compress, to_compressed, to_uncompressed, encode_point
+ *   eccx_point_decompress[_dev]  PointAffine::decompress, from_compressed[_oncurve_only],
+ *                              from_uncompressed[_oncurve_only], decode_point
+ *                              curve_macros.rs:211-223, src/curve/affine.rs:23-58,
+ *                              src/curve/bls12_381/serialize.rs:253-383, src/protocol/ed25519.rs:27-59
  *
  * Byte conventions are the reference's:
  *   - Weierstrass curves (p256r1, p384r1, p521r1, BLS12-381 G1): field elements and

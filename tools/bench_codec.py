@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Throughput of the point codecs (eccx_point_compress_dev / eccx_point_decompress_dev) on one
-GPU, inputs resident in HBM: one JSON line per curve and direction.
+"""Throughput of the point codecs (eccx_point_compress_dev / eccx_point_decompress_dev) and of the
+group law (eccx_point_add_dev) on one GPU, inputs resident in HBM: one JSON line per curve and direction.
 
 usage: python tools/bench_codec.py [--log2n 20] [--steps 10]
 `achieved` = algorithmic bytes (encoding + x||y + flag byte) per launch / average launch time
@@ -42,7 +42,10 @@ def main():
         s_pts = pts[idx].cpu().numpy().tobytes()
         ok = enc[idx].cpu().numpy().tobytes() == R.point_compress_bytes(curve, s_pts) and torch.equal(back, pts) \
             and int(bfl.sum()) == 0
-        for name, fn in (("compress", lambda: eng.point_compress_t(curve, pts, inf, enc)),
+        other, ofl = eng.scalarmul_base_t(curve, torch.from_numpy(W.random_scalars(curve, n, seed=4)).to(dev))
+        sums, sfl = eng.point_add_t(curve, pts, other)
+        for name, fn in (("add", lambda: eng.point_add_t(curve, pts, other, sums, sfl)),
+                         ("compress", lambda: eng.point_compress_t(curve, pts, inf, enc)),
                          ("decompress", lambda: eng.point_decompress_t(curve, enc, back, bfl)),
                          ("decompress+subgroup", (lambda: eng.point_decompress_t(curve, enc, back, bfl, check_subgroup=True))
                           if curve == "bls12_381_g1" else None)):
@@ -57,7 +60,7 @@ def main():
                 b.record(stream)
             torch.cuda.synchronize(dev)
             ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
-            alg = eb + 2 * fb + 1
+            alg = 6 * fb + 1 if name == "add" else eb + 2 * fb + 1
             print(json.dumps({"metric": f"{curve} point {name}", "value": n / (ms * 1e-3), "unit": "points/s", "n": n,
                               "kernel_ms": ms, "alg_bytes_per_unit": alg,
                               "roofline": {"bound": "hbm", "achieved": alg * n / (ms * 1e-3) / 1e9, "peak": 8000.0,
