@@ -27,6 +27,7 @@ constexpr uint32_t K_BASE_IS_GENERATOR = 1u << 0;
 constexpr uint32_t K_OUT_TABLE = 1u << 1;
 constexpr uint32_t K_VALIDATE = 1u << 2;
 constexpr uint32_t K_OUT_ROWS = 1u << 3;
+constexpr uint32_t K_NEGATE_B = 1u << 5;  // second operand negated: a - b, u1*G - u2*Q
 
 const CurveOps* ops_of(int curve) {
   switch (curve) {
@@ -594,11 +595,14 @@ int eccx_point_add_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_a, cons
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc = ensure_rows(ctx, ops, n);
   if (rc) return rc;
-  HIP_TRY(ctx, ops->point_add(flat_grid(ctx, n), s, n, static_cast<const uint8_t*>(d_a), static_cast<const uint8_t*>(d_a_inf),
-                              static_cast<const uint8_t*>(d_b), static_cast<const uint8_t*>(d_b_inf), ctx->jac,
-                              static_cast<uint8_t*>(d_flags), (opts & ECCX_SUBTRACT) ? (1u << 5) : 0u));
-  HIP_TRY(ctx, ops->to_affine_hom(norm_grid(ctx, n), s, n, ctx->jac, static_cast<uint8_t*>(d_out),
-                                  static_cast<uint8_t*>(d_flags)));
+  // default: complete addition on the unsaturated field; ECCX_MIRROR_REFERENCE: the saturated pair
+  const bool mirror = (opts & ECCX_MIRROR_REFERENCE) != 0 || !ops->point_add_u;
+  HIP_TRY(ctx, (mirror ? ops->point_add : ops->point_add_u)(
+                   flat_grid(ctx, n), s, n, static_cast<const uint8_t*>(d_a), static_cast<const uint8_t*>(d_a_inf),
+                   static_cast<const uint8_t*>(d_b), static_cast<const uint8_t*>(d_b_inf), ctx->jac,
+                   static_cast<uint8_t*>(d_flags), (opts & ECCX_SUBTRACT) ? K_NEGATE_B : 0u));
+  HIP_TRY(ctx, (mirror ? ops->to_affine_hom : ops->to_affine_add_u)(norm_grid(ctx, n), s, n, ctx->jac, static_cast<uint8_t*>(d_out),
+                                                                    static_cast<uint8_t*>(d_flags)));
   return ECCX_OK;
 }
 
@@ -759,7 +763,7 @@ int eccx_double_scalarmul_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_
   if (rc) return rc;
   rc = ensure_rows(ctx, ops, n);
   if (rc) return rc;
-  const uint32_t kopts = kopts_of(opts) | ((opts & ECCX_SUBTRACT) ? (1u << 5) : 0u);
+  const uint32_t kopts = kopts_of(opts) | ((opts & ECCX_SUBTRACT) ? K_NEGATE_B : 0u);
   HIP_TRY(ctx, ops->var_fused(grid, s, n, static_cast<const uint8_t*>(d_u2), static_cast<const uint8_t*>(d_q), ctx->jac,
                               static_cast<uint8_t*>(d_flags), ctx->scratch, kopts, static_cast<const uint8_t*>(d_u1),
                               ctx->comb_u[curve]));

@@ -1189,12 +1189,82 @@ __global__ void __launch_bounds__(ED_LDS_BLOCK) k_ed_scalarmul_base_lds6(size_t 
   }
 }
 
+// ---- group law on affine inputs (eccx_point_add) -----------------------------------------------
+//   impl Add / Sub / Neg for Point, CurveGroup::double   src/curve/fiat/curve_macros.rs:297-411,
+//   src/curve/group.rs:28-70 -> the complete RCB addition (projective.rs:340-423 / :268-338), which
+//   also covers a == b, a == -b and the point at infinity; edwards25519: Point::add
+//   (curve25519.rs:695-710).  Same formulas as the saturated k_point_add / k_ed_point_add
+//   (kernels.hpp, kept as the ECCX_MIRROR_REFERENCE variant), on the unsaturated field; rows of
+//   (X, Y, Z) for k_batch_to_affine_unsat<NORM_HOMOGENEOUS / NORM_EDWARDS>.
+template <class CU>
+__global__ void __launch_bounds__(WG) k_point_add_unsat(size_t n, const uint8_t* __restrict__ a, const uint8_t* __restrict__ a_inf,
+                                                        const uint8_t* __restrict__ b, const uint8_t* __restrict__ b_inf,
+                                                        uint32_t* __restrict__ rows_out, uint8_t* __restrict__ flags, uint32_t opts) {
+  using CS = typename CU::Sat;
+  constexpr int L = CS::L;
+  constexpr int FB = CS::FB;
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n; i += (size_t)gridDim.x * WG) {
+    U<CU, 1, 3> one;
+#pragma unroll
+    for (int k = 0; k < CU::N; ++k) one.v[k] = CU::ONE[k];
+    auto load = [&](UPt<CU>& p, const uint8_t* __restrict__ src, bool inf, bool negate) {
+      Fe<L> raw;
+      fe_load_be<CS>(raw, src);
+      p.x = u_as<1, 3>(u_to_mont<CU>(raw));
+      fe_load_be<CS>(raw, src + FB);
+      p.y = u_as<1, 3>(u_to_mont<CU>(raw));
+      if (negate) p.y = u_reduce(u_neg(p.y));
+      p.z = one;
+      if (inf) {  // (0 : 1 : 0), projective.rs:152-156
+        u_set_zero(p.x);
+        p.y = one;
+        u_set_zero(p.z);
+      }
+    };
+    UPt<CU> p, q, r;
+    load(p, a + i * (size_t)(2 * FB), a_inf && a_inf[i] == 1, false);
+    load(q, b + i * (size_t)(2 * FB), b_inf && b_inf[i] == 1, (opts & OPT_NEGATE_B) != 0);
+    upt_add<CU>(r, p, q);
+    u3_store<CU>(rows_out + i * (size_t)urow3_words<CU>(), r.x, r.y, r.z);
+    flags[i] = ((a_inf && a_inf[i] == 2) || (b_inf && b_inf[i] == 2)) ? 2 : 0;  // rejected operands stay rejected
+  }
+}
+
+template <class CU>
+__global__ void __launch_bounds__(WG) k_ed_point_add_unsat(size_t n, const uint8_t* __restrict__ a, const uint8_t* __restrict__ a_fl,
+                                                           const uint8_t* __restrict__ b, const uint8_t* __restrict__ b_fl,
+                                                           uint32_t* __restrict__ rows_out, uint8_t* __restrict__ flags, uint32_t opts) {
+  using CS = typename CU::Sat;
+  constexpr int L = CS::L;
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n; i += (size_t)gridDim.x * WG) {
+    auto load = [&](UEd<CU>& p, const uint8_t* __restrict__ src) {  // from_affine, curve25519.rs:638-645
+      Fe<L> raw;
+      fe_load_le<CS>(raw, src);
+      p.x = u_reduce(u_as<1, 3>(u_from_sat<CU>(raw)));
+      fe_load_le<CS>(raw, src + 32);
+      p.y = u_reduce(u_as<1, 3>(u_from_sat<CU>(raw)));
+      u_set_zero(p.z);
+      p.z.v[0] = 1;
+      p.t = u_fit<1, 3>(u_mul(p.x, p.y));
+    };
+    UEd<CU> p, q, r;
+    load(p, a + i * 64);
+    load(q, b + i * 64);
+    UEdCached<CU> c;
+    ued_cache<CU>(c, q);
+    ued_add<CU, false>(r, p, c, (opts & OPT_NEGATE_B) != 0);  // -(x, y) = (-x, y): the cached form swaps y -+ x
+    u3_store<CU>(rows_out + i * (size_t)urow3_words<CU>(), r.x, r.y, r.z);
+    flags[i] = ((a_fl && a_fl[i] == 2) || (b_fl && b_fl[i] == 2)) ? 2 : 0;
+  }
+}
+
 // ---- batched normalisation on the unsaturated field ----------------------------------------------
 // Point::to_affine (projective.rs:655-682; curve25519.rs:663-666, :529-532) for a whole batch of
 // rows written by the kernels above (X, Y, Z as tight digits of the working form).  Thread t of a
 // workgroup handles units tile + u*WG + t, u = 0..U-1, with ONE inversion (Montgomery's trick),
 // by division steps (inv_gcd.hpp).  Modes as for k_batch_to_affine (kernels_fast.hpp):
-//   NORM_JACOBIAN     x = X/Z^2, y = Y/Z^3, big-endian bytes; Z = 0 (all-zero limbs) is infinity
+//   NORM_HOMOGENEOUS  x = X/Z, y = Y/Z, big-endian bytes; Z = 0 is infinity (rows of the group law)
+//   NORM_JACOBIAN     x = X/Z^2, y = Y/Z^3, big-endian bytes; Z = 0 is infinity
 //   NORM_EDWARDS      x = X/Z, y = Y/Z, little-endian bytes, flag 1 = neutral element
 //   NORM_MONTGOMERY_U u = X/Z with 0 for Z = 0 (mod p), 32 little-endian bytes, flag 1 = zero result
 // flags[i] on entry: 2 marks a rejected input (kept, zero output).
@@ -1206,7 +1276,7 @@ __global__ void __launch_bounds__(WG) k_batch_to_affine_unsat(size_t n, const ui
   constexpr int FB = CS::FB;
   constexpr int W3 = urow3_words<CU>();
   using T = U<CU, 1, 3>;
-  static_assert(MODE == NORM_JACOBIAN || MODE == NORM_EDWARDS || MODE == NORM_MONTGOMERY_U, "mode");
+  static_assert(MODE == NORM_HOMOGENEOUS || MODE == NORM_JACOBIAN || MODE == NORM_EDWARDS || MODE == NORM_MONTGOMERY_U, "mode");
   const size_t tile_units = (size_t)WG * UN;
   for (size_t tile = (size_t)blockIdx.x * tile_units; tile < n; tile += (size_t)gridDim.x * tile_units) {
     T one;
@@ -1260,7 +1330,7 @@ __global__ void __launch_bounds__(WG) k_batch_to_affine_unsat(size_t n, const ui
         u_to_canonical<CU>(ay, u_mul(y, u_mul(zi2, zi)));
       } else {
         u_to_canonical<CU>(ax, u_mul(x, zi));
-        if constexpr (MODE == NORM_EDWARDS) u_to_canonical<CU>(ay, u_mul(y, zi));
+        if constexpr (MODE == NORM_EDWARDS || MODE == NORM_HOMOGENEOUS) u_to_canonical<CU>(ay, u_mul(y, zi));
       }
       if (i < n) {
         const bool rejected = flags[i] == 2;

@@ -75,6 +75,11 @@ struct CurveOps {
   // the zcash uncompressed flavour, 2 FB bytes per point (bls12_381_g1 only, else null)
   hipError_t (*decompress_raw)(int grid, hipStream_t s, size_t n, const uint8_t* enc, uint8_t* out, uint8_t* flags);
   hipError_t (*compress_raw)(int grid, hipStream_t s, size_t n, const uint8_t* xy, const uint8_t* inf, uint8_t* out);
+  // group law on the unsaturated field (default; point_add / to_affine_hom are the saturated,
+  // reference-mirroring pair) and the normalisation of its (X, Y, Z) rows
+  hipError_t (*point_add_u)(int grid, hipStream_t s, size_t n, const uint8_t* a, const uint8_t* a_inf, const uint8_t* b,
+                            const uint8_t* b_inf, uint32_t* rows, uint8_t* flags, uint32_t opts);
+  hipError_t (*to_affine_add_u)(int grid, hipStream_t s, size_t n, const uint32_t* rows, uint8_t* out, uint8_t* flags);
 };
 // units normalised per lane with one inversion: 16 where the prefix products fit the register
 // file (8-limb fields), 8 above

@@ -127,9 +127,10 @@ class Engine:
         return res + (proj.raw[: n * _proj_width(cid)],) if want_proj else res
 
     def point_add(self, curve, a: bytes, b: bytes, *, a_inf: Optional[bytes] = None, b_inf: Optional[bytes] = None,
-                  subtract: bool = False):
+                  subtract: bool = False, mirror: bool = False):
         """Batched group law out[i] = a[i] + b[i] (a[i] - b[i] with subtract=True) on affine points;
-        a_inf / b_inf flag operands that are the point at infinity.  Returns (affine bytes, flags)."""
+        a_inf / b_inf flag operands that are the point at infinity.  Returns (affine bytes, flags).
+        mirror=True runs the saturated-limb kernels instead of the default unsaturated ones."""
         cid = curve_id(curve)
         fb = field_bytes(cid)
         if len(a) != len(b) or len(a) % (2 * fb):
@@ -137,7 +138,8 @@ class Engine:
         n = len(a) // (2 * fb)
         out = ctypes.create_string_buffer(max(1, n * 2 * fb))
         flags = ctypes.create_string_buffer(max(1, n))
-        rc = self._lib.eccx_point_add(self._ctx, cid, n, a, a_inf, b, b_inf, out, flags, SUBTRACT if subtract else 0)
+        rc = self._lib.eccx_point_add(self._ctx, cid, n, a, a_inf, b, b_inf, out, flags,
+                                      (SUBTRACT if subtract else 0) | (MIRROR_REFERENCE if mirror else 0))
         self._check(rc)
         return out.raw[: n * 2 * fb], flags.raw[:n]
 
@@ -248,7 +250,7 @@ class Engine:
         return out.raw[: n * 32], flags.raw[:n]
 
     def point_add_t(self, curve, a, b, out=None, flags=None, *, a_inf=None, b_inf=None, subtract: bool = False,
-                    stream: Optional[int] = None):
+                    mirror: bool = False, stream: Optional[int] = None):
         """Device-tensor form of point_add (torch.uint8 CUDA tensors): out[i] = a[i] +- b[i]."""
         import torch
 
@@ -268,7 +270,8 @@ class Engine:
             stream = torch.cuda.current_stream(a.device).cuda_stream
         rc = self._lib.eccx_point_add_dev(self._ctx, cid, n, a.data_ptr(), a_inf.data_ptr() if a_inf is not None else None,
                                           b.data_ptr(), b_inf.data_ptr() if b_inf is not None else None,
-                                          out.data_ptr(), flags.data_ptr(), SUBTRACT if subtract else 0, stream)
+                                          out.data_ptr(), flags.data_ptr(),
+                                          (SUBTRACT if subtract else 0) | (MIRROR_REFERENCE if mirror else 0), stream)
         self._check(rc)
         return out, flags
 

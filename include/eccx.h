@@ -143,7 +143,9 @@ int eccx_scalarmul_base_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_sc
  * point at infinity, so double(a) is eccx_point_add(a, a) and neg(a) is infinity - a.
  *   a, b        : n x 2FB affine x||y (host memory)
  *   a_inf, b_inf: NULL, or n flag bytes (1 = that operand is the point at infinity; Weierstrass only)
- *   out, flags  : as for eccx_scalarmul_var */
+ *   out, flags  : as for eccx_scalarmul_var
+ * Default kernels: the complete addition on the unsaturated field; ECCX_MIRROR_REFERENCE selects
+ * the saturated-limb pair (same formulas, same bytes out). */
 int eccx_point_add(eccx_ctx* ctx, int curve, size_t n, const uint8_t* a, const uint8_t* a_inf, const uint8_t* b,
                    const uint8_t* b_inf, uint8_t* out, uint8_t* flags, uint32_t opts);
 /* Device-buffer form (d_a_inf / d_b_inf may be NULL), enqueued on `stream` without synchronising. */

@@ -40,8 +40,8 @@ def test_point_add_weierstrass(engine, oracle, curve):
             return None
         return (int.from_bytes(buf[i * pb:i * pb + c.fb], "big"), int.from_bytes(buf[i * pb + c.fb:(i + 1) * pb], "big"))
 
-    for subtract in (False, True):
-        out, flags = engine.point_add(curve, A, B, a_inf=bytes(a_inf), b_inf=bytes(b_inf), subtract=subtract)
+    for subtract, mirror in ((False, False), (True, False), (False, True), (True, True)):
+        out, flags = engine.point_add(curve, A, B, a_inf=bytes(a_inf), b_inf=bytes(b_inf), subtract=subtract, mirror=mirror)
         for i in range(n):
             P, Q = pt(A, a_inf, i), pt(B, b_inf, i)
             if subtract and Q is not None:
@@ -72,8 +72,8 @@ def test_point_add_ed25519(engine, oracle):
     B[64:128] = ((-x) % c.p).to_bytes(32, "little") + A[96:128]                 # A + (-A) = neutral
     B[128:192] = (0).to_bytes(32, "little") + (1).to_bytes(32, "little")        # A + neutral
     B = bytes(B)
-    for subtract in (False, True):
-        out, flags = engine.point_add("ed25519", A, B, subtract=subtract)
+    for subtract, mirror in ((False, False), (True, False), (False, True), (True, True)):
+        out, flags = engine.point_add("ed25519", A, B, subtract=subtract, mirror=mirror)
         for i in range(n):
             P = (int.from_bytes(A[i * 64:i * 64 + 32], "little"), int.from_bytes(A[i * 64 + 32:(i + 1) * 64], "little"))
             Q = (int.from_bytes(B[i * 64:i * 64 + 32], "little"), int.from_bytes(B[i * 64 + 32:(i + 1) * 64], "little"))
@@ -111,3 +111,6 @@ def test_point_add_device_tensors(engine, oracle, curve):
                                                 subtract=subtract, stream=stream.cuda_stream)
             stream.synchronize()
             assert out.cpu().numpy().tobytes() == want[0] and flags.cpu().numpy().tobytes() == want[1], (subtract, with_inf)
+            # the saturated-limb kernels give the same bytes
+            assert want == engine.point_add(curve, A, B, a_inf=a_inf if with_inf else None, b_inf=b_inf if with_inf else None,
+                                            subtract=subtract, mirror=True)

@@ -83,8 +83,12 @@ def main():
             a_inf = None if curve == "ed25519" else f_mir.cpu().numpy().tobytes()
             b_inf = None if curve == "ed25519" else vf_mir.cpu().numpy().tobytes()
             s_out, s_fl = eng.point_add(curve, b_mir.cpu().numpy().tobytes(), v_mir.cpu().numpy().tobytes(),
-                                        a_inf=a_inf, b_inf=b_inf, subtract=subtract)
+                                        a_inf=a_inf, b_inf=b_inf, subtract=subtract, mirror=True)
             assert d_out.cpu().numpy().tobytes() == s_out and d_fl.cpu().numpy().tobytes() == s_fl, ("dsm", curve, n, subtract, rounds)
+            # the default (unsaturated) group law against the saturated one
+            u_out, u_fl = eng.point_add(curve, b_mir.cpu().numpy().tobytes(), v_mir.cpu().numpy().tobytes(),
+                                        a_inf=a_inf, b_inf=b_inf, subtract=subtract)
+            assert (u_out, u_fl) == (s_out, s_fl), ("point_add", curve, n, subtract, rounds)
         # wire formats: compress -> decompress gives the points back; the other sign gives the
         # negated point (their sum is the neutral element), except where the flipped encoding is
         # not canonical (edwards25519 x = 0) and must be rejected
