@@ -345,10 +345,65 @@ ECCX_DEV void fe_from_mont(Fe<C::L>& r, const Fe<C::L>& a) {
 }
 
 // ---- byte I/O -----------------------------------------------------------------
+// Field elements cross the ABI as FB big-endian (Weierstrass) or little-endian (edwards25519)
+// bytes, one record per lane.  Where FB is a multiple of 4 and the address allows it the bytes
+// move as 16-byte or 4-byte words (a lane's record is contiguous, so a wavefront's accesses
+// fill whole cache lines in a few instructions instead of FB byte accesses per lane); any
+// other address, and the 66-byte P-521 elements, take the byte path.
+template <int W>
+ECCX_DEV bool io_words_load(uint32_t (&w)[W], const uint8_t* __restrict__ in) {
+  const uintptr_t addr = reinterpret_cast<uintptr_t>(in);
+  if constexpr (W % 4 == 0) {
+    if ((addr & 15u) == 0) {
+      const uint4* q = reinterpret_cast<const uint4*>(in);
+#pragma unroll
+      for (int i = 0; i < W / 4; ++i) {
+        const uint4 v = q[i];
+        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+      }
+      return true;
+    }
+  }
+  if ((addr & 3u) == 0) {
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(in);
+#pragma unroll
+    for (int i = 0; i < W; ++i) w[i] = q[i];
+    return true;
+  }
+  return false;
+}
+template <int W>
+ECCX_DEV bool io_words_store(uint8_t* __restrict__ out, const uint32_t (&w)[W]) {
+  const uintptr_t addr = reinterpret_cast<uintptr_t>(out);
+  if constexpr (W % 4 == 0) {
+    if ((addr & 15u) == 0) {
+      uint4* q = reinterpret_cast<uint4*>(out);
+#pragma unroll
+      for (int i = 0; i < W / 4; ++i) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+      return true;
+    }
+  }
+  if ((addr & 3u) == 0) {
+    uint32_t* q = reinterpret_cast<uint32_t*>(out);
+#pragma unroll
+    for (int i = 0; i < W; ++i) q[i] = w[i];
+    return true;
+  }
+  return false;
+}
+
 // big-endian FB bytes -> integer limbs (no range check, like from_bytes_unchecked_be,
 // field_macros.rs:581-596)
 template <class C>
 ECCX_DEV void fe_load_be(Fe<C::L>& r, const uint8_t* __restrict__ in) {
+  if constexpr (C::FB % 4 == 0 && C::FB == 4 * C::L) {
+    uint32_t w[C::L];
+    if (io_words_load<C::L>(w, in)) {
+#pragma unroll
+      for (int i = 0; i < C::L; ++i) r.v[i] = __builtin_bswap32(w[C::L - 1 - i]);
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < C::L; ++i) {
     uint32_t w = 0;
@@ -362,6 +417,12 @@ ECCX_DEV void fe_load_be(Fe<C::L>& r, const uint8_t* __restrict__ in) {
 }
 template <class C>
 ECCX_DEV void fe_store_be(uint8_t* __restrict__ out, const Fe<C::L>& a) {
+  if constexpr (C::FB % 4 == 0 && C::FB == 4 * C::L) {
+    uint32_t w[C::L];
+#pragma unroll
+    for (int i = 0; i < C::L; ++i) w[i] = __builtin_bswap32(a.v[C::L - 1 - i]);
+    if (io_words_store<C::L>(out, w)) return;
+  }
 #pragma unroll
   for (int i = 0; i < C::L; ++i) {
 #pragma unroll
@@ -373,6 +434,9 @@ ECCX_DEV void fe_store_be(uint8_t* __restrict__ out, const Fe<C::L>& a) {
 }
 template <class C>
 ECCX_DEV void fe_load_le(Fe<C::L>& r, const uint8_t* __restrict__ in) {
+  if constexpr (C::FB % 4 == 0 && C::FB == 4 * C::L) {
+    if (io_words_load<C::L>(r.v, in)) return;
+  }
 #pragma unroll
   for (int i = 0; i < C::L; ++i) {
     uint32_t w = 0;
@@ -386,6 +450,9 @@ ECCX_DEV void fe_load_le(Fe<C::L>& r, const uint8_t* __restrict__ in) {
 }
 template <class C>
 ECCX_DEV void fe_store_le(uint8_t* __restrict__ out, const Fe<C::L>& a) {
+  if constexpr (C::FB % 4 == 0 && C::FB == 4 * C::L) {
+    if (io_words_store<C::L>(out, a.v)) return;
+  }
 #pragma unroll
   for (int i = 0; i < C::L; ++i) {
 #pragma unroll

@@ -533,3 +533,39 @@ def test_sharded_entry_point_single_gpu(engine, oracle):
     assert rc == 0
     want = oracle.var("p256r1", ks, pts)
     assert out.raw == want[0] and fl.raw == want[1]
+
+
+@pytest.mark.parametrize("curve", ["p256r1", "p384r1", "ed25519"])
+def test_device_buffers_at_any_alignment(engine, oracle, curve):
+    """Field elements move as 16-byte words, 4-byte words or bytes depending on the address
+    (fe.hpp byte I/O): tensor views at offsets 0, 1, 2, 4, 8 and 12 give the same bytes."""
+    import torch
+
+    fb, sb = sizes(curve)
+    n = 700
+    ks = W.random_scalars(curve, n, seed=5).tobytes()
+    pts = bases(oracle, curve, n, seed=6)
+    want_v = oracle.var(curve, ks, pts)
+    want_b = oracle.base(curve, ks)
+    dev = torch.device("cuda", 0)
+
+    def view(data, off, fill=0):
+        buf = torch.full((len(data) + 64,), fill, dtype=torch.uint8, device=dev)
+        buf[off:off + len(data)] = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
+        return buf, buf[off:off + len(data)]
+
+    for off in (0, 1, 2, 4, 8, 12):
+        _, k_t = view(ks, off)
+        _, p_t = view(pts, (off * 3) % 16)
+        obuf, o_t = view(bytes(n * 2 * fb), off, fill=0xAA)
+        fbuf, f_t = view(bytes(n), (off + 1) % 16, fill=0xAA)
+        engine.scalarmul_var_t(curve, k_t, p_t, o_t, f_t)
+        torch.cuda.synchronize()
+        assert o_t.cpu().numpy().tobytes() == want_v[0] and f_t.cpu().numpy().tobytes() == want_v[1], off
+        assert bool((obuf[:off] == 0xAA).all()) and bool((obuf[off + n * 2 * fb:] == 0xAA).all())
+        engine.scalarmul_base_t(curve, k_t, o_t, f_t)
+        torch.cuda.synchronize()
+        assert o_t.cpu().numpy().tobytes() == want_b[0] and f_t.cpu().numpy().tobytes() == want_b[1], off
+        s_t, sf_t = engine.point_add_t(curve, p_t, o_t)
+        torch.cuda.synchronize()
+        assert (s_t.cpu().numpy().tobytes(), sf_t.cpu().numpy().tobytes()) == engine.point_add(curve, pts, want_b[0])
