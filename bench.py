@@ -105,14 +105,14 @@ WORKLOADS = {
 # read from inside this process, so the figure is the committed measurement of this very
 # workload, not a live one; null where no profile has been taken.
 MEASURED_TRAFFIC = {
-    "p256r1_var_2^20": {"bytes": 2 * (6806181156 + 110009232) + 3673585499 + 70260848,
-                        "fetch_raw": 6806181156 + 110009232, "write": 3673585499 + 70260848,
+    "p256r1_var_2^20": {"bytes": 2 * (6786535305 + 109929528) + 3698666166 + 70295648,
+                        "fetch_raw": 6786535305 + 109929528, "write": 3698666166 + 70295648,
                         "source": "profiles/r01_p256r1_var_u29.json"},
-    "ed25519_base_2^20": {"bytes": 2 * (1133845141 + 108967085) + 118731472 + 70264914,
-                          "fetch_raw": 1133845141 + 108967085, "write": 118731472 + 70264914,
+    "ed25519_base_2^20": {"bytes": 2 * (1135026666 + 108984009) + 118721354 + 70266038,
+                          "fetch_raw": 1135026666 + 108984009, "write": 118721354 + 70266038,
                           "source": "profiles/r01_ed25519_base.json"},
-    "x25519_2^20": {"bytes": 2 * (31295085 + 106660900) + 118496251 + 36701193,
-                    "fetch_raw": 31295085 + 106660900, "write": 118496251 + 36701193,
+    "x25519_2^20": {"bytes": 2 * (31830262 + 106681508) + 118489737 + 36701348,
+                    "fetch_raw": 31830262 + 106681508, "write": 118489737 + 36701348,
                     "source": "profiles/r01_x25519.json"},
 }
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
