@@ -28,15 +28,17 @@ def trace(db_path):
     agg = {}
     for name, grid, wg, dur, vgpr, agpr, sgpr, scratch, lds in rows:
         k = (short(name), grid, wg)
-        a = agg.setdefault(k, {"calls": 0, "sum": 0, "min": 1e30, "max": 0, "vgpr": vgpr, "agpr": agpr, "sgpr": sgpr, "scratch": scratch, "lds": lds})
+        a = agg.setdefault(k, {"calls": 0, "sum": 0, "min": 1e30, "max": 0, "durs": [], "vgpr": vgpr, "agpr": agpr, "sgpr": sgpr, "scratch": scratch, "lds": lds})
         a["calls"] += 1
+        a["durs"].append(dur)
         a["sum"] += dur
         a["min"] = min(a["min"], dur)
         a["max"] = max(a["max"], dur)
     out = []
     for (name, grid, wg), a in sorted(agg.items(), key=lambda kv: -kv[1]["sum"]):
         out.append({"kernel": name, "grid_threads": grid, "workgroup": wg, "calls": a["calls"],
-                    "avg_us": a["sum"] / a["calls"] / 1e3, "min_us": a["min"] / 1e3, "max_us": a["max"] / 1e3,
+                    "avg_us": a["sum"] / a["calls"] / 1e3, "median_us": sorted(a["durs"])[len(a["durs"]) // 2] / 1e3,
+                    "min_us": a["min"] / 1e3, "max_us": a["max"] / 1e3,
                     "total_us": a["sum"] / 1e3, "vgpr": a["vgpr"], "agpr": a["agpr"], "sgpr": a["sgpr"],
                     "scratch_bytes": a["scratch"], "lds_bytes": a["lds"]})
     return out
