@@ -73,6 +73,11 @@ hipError_t point_add_(int grid, hipStream_t s, size_t n, const uint8_t* a, const
   hipLaunchKernelGGL(k_ed_point_add<ED25519>, dim3(grid), dim3(WG), 0, s, n, a, a_fl, b, b_fl, rows, flags, opts);
   return hipGetLastError();
 }
+hipError_t to_affine_add_u_(int grid, hipStream_t s, size_t n, const uint32_t* rows, uint8_t* out, uint8_t* flags) {
+  hipLaunchKernelGGL((k_batch_to_affine_unsat<ED25519U, NORM_EDWARDS, to_affine_add_u(ED25519::L)>), dim3(grid), dim3(WG), 0, s, n, rows,
+                     out, flags);
+  return hipGetLastError();
+}
 hipError_t point_add_u_(int grid, hipStream_t s, size_t n, const uint8_t* a, const uint8_t* a_fl, const uint8_t* b,
                         const uint8_t* b_fl, uint32_t* rows, uint8_t* flags, uint32_t opts) {
   hipLaunchKernelGGL(k_ed_point_add_unsat<ED25519U>, dim3(grid), dim3(WG), 0, s, n, a, a_fl, b, b_fl, rows, flags, opts);
@@ -100,7 +105,7 @@ hipError_t launch_x25519_to_u(int grid, hipStream_t s, size_t n, const uint32_t*
 const CurveOps& ops_ED25519() {
   static const CurveOps o = {{ED25519::FB, ED25519::SB, ED25519::L, 4 * ED25519::L, 0, 1, ED_VAR_ROW_WORDS,
                               (urow3_words<ED25519U>() > row_words<ED25519::L>() ? urow3_words<ED25519U>() : row_words<ED25519::L>())}, var_, base_, var_fast_, base_lds_, to_affine_hom_, var_grid_, var_fast_grid_, to_affine_var_, point_add_, ED_U_ENTRY_WORDS, comb_bits<ED25519U>(), comb_convert_, base_w8_, ED_LDS_BITS, ED_LDS_WINDOWS, ED_LDS_DIGITS, ED_LDS_ENTRY_WORDS, lds_convert_, var_fused_, 32, decompress_, compress_, nullptr, nullptr,
-                              point_add_u_, to_affine_var_};
+                              point_add_u_, to_affine_add_u_};
   return o;
 }
 }  // namespace eccx

@@ -84,6 +84,15 @@ struct CurveOps {
 // units normalised per lane with one inversion: 16 where the prefix products fit the register
 // file (8-limb fields), 8 above
 constexpr int to_affine_u(int limbs) { return limbs <= 8 ? ECCX_NORM_U8 : ECCX_NORM_UBIG; }
+// the same for the rows of the group law, whose producer is short: the normalisation is most of
+// the operation there
+#ifndef ECCX_NORM_ADD_U8
+#define ECCX_NORM_ADD_U8 ECCX_NORM_U8
+#endif
+#ifndef ECCX_NORM_ADD_UBIG
+#define ECCX_NORM_ADD_UBIG ECCX_NORM_UBIG
+#endif
+constexpr int to_affine_add_u(int limbs) { return limbs <= 8 ? ECCX_NORM_ADD_U8 : ECCX_NORM_ADD_UBIG; }
 
 const CurveOps& ops_P256();
 const CurveOps& ops_P384();

@@ -193,12 +193,13 @@ class Engine:
         return out.raw[: n * eb]
 
     def point_decompress_t(self, curve, enc, out=None, flags=None, *, check_subgroup: bool = False,
-                           stream: Optional[int] = None):
+                           uncompressed: bool = False, stream: Optional[int] = None):
         """Device-tensor form of point_decompress (torch.uint8 CUDA tensors)."""
         import torch
 
         cid = curve_id(curve)
-        fb, eb = field_bytes(cid), self.compressed_bytes(cid)
+        fb = field_bytes(cid)
+        eb = 2 * fb if uncompressed else self.compressed_bytes(cid)
         n = enc.numel() // eb
         if out is None:
             out = torch.empty((n, 2 * fb), dtype=torch.uint8, device=enc.device)
@@ -212,15 +213,17 @@ class Engine:
         if stream is None:
             stream = torch.cuda.current_stream(enc.device).cuda_stream
         self._check(self._lib.eccx_point_decompress_dev(self._ctx, cid, n, enc.data_ptr(), out.data_ptr(), flags.data_ptr(),
-                                                        CHECK_SUBGROUP if check_subgroup else 0, stream))
+                                                        (CHECK_SUBGROUP if check_subgroup else 0)
+                                                        | (UNCOMPRESSED if uncompressed else 0), stream))
         return out, flags
 
-    def point_compress_t(self, curve, xy, inf=None, out=None, *, stream: Optional[int] = None):
+    def point_compress_t(self, curve, xy, inf=None, out=None, *, uncompressed: bool = False, stream: Optional[int] = None):
         """Device-tensor form of point_compress (torch.uint8 CUDA tensors)."""
         import torch
 
         cid = curve_id(curve)
-        fb, eb = field_bytes(cid), self.compressed_bytes(cid)
+        fb = field_bytes(cid)
+        eb = 2 * fb if uncompressed else self.compressed_bytes(cid)
         n = xy.numel() // (2 * fb)
         if out is None:
             out = torch.empty((n, eb), dtype=torch.uint8, device=xy.device)
@@ -232,7 +235,8 @@ class Engine:
         if stream is None:
             stream = torch.cuda.current_stream(xy.device).cuda_stream
         self._check(self._lib.eccx_point_compress_dev(self._ctx, cid, n, xy.data_ptr(),
-                                                      inf.data_ptr() if inf is not None else None, out.data_ptr(), 0, stream))
+                                                      inf.data_ptr() if inf is not None else None, out.data_ptr(),
+                                                      UNCOMPRESSED if uncompressed else 0, stream))
         return out
 
     def x25519(self, scalars: bytes, u: Optional[bytes] = None, *, raw_ladder: bool = False):

@@ -282,6 +282,16 @@ def test_zcash_uncompressed_flavour(engine, oracle):
             assert out[96 * i:96 * i + 96] == (bytes(96) if P is None else P[0].to_bytes(48, "big") + P[1].to_bytes(48, "big")), (i, chk)
     with pytest.raises(Exception):
         engine.point_compress("p256r1", bytes(64), uncompressed=True)
+    # device-tensor forms
+    import torch
+
+    dev = torch.device("cuda", 0)
+    t = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    raw_t = engine.point_compress_t(curve, t(xy).reshape(n, -1), t(bytes(inf)), uncompressed=True)
+    back_t, fl_t = engine.point_decompress_t(curve, raw_t, uncompressed=True)
+    torch.cuda.synchronize()
+    assert raw_t.cpu().numpy().tobytes() == raw
+    assert (back_t.cpu().numpy().tobytes(), fl_t.cpu().numpy().tobytes()) == engine.point_decompress(curve, raw, uncompressed=True)
 
 
 @pytest.mark.gpu
