@@ -138,6 +138,13 @@ def main():
                           "base", bad[i].cpu().numpy().tobytes().hex(), "default", o1[i].cpu().numpy().tobytes().hex(), int(f1[i]),
                           "mirror", o2[i].cpu().numpy().tobytes().hex(), int(f2[i]), flush=True)
             assert torch.equal(o1, o2) and torch.equal(f1, f2), ("validate", curve, n, rounds)
+            # without validation the corrupted units are garbage in, garbage out -- but only they:
+            # every untouched unit must come out as before from both stacks
+            o4, f4 = eng.scalarmul_var_t(curve, k2, bad)
+            o5, f5 = eng.scalarmul_var_t(curve, k2, bad, mirror=True)
+            keep = ~sel
+            assert torch.equal(o4[keep], v_def[keep]) and torch.equal(f4[keep], vf_def[keep]), ("garbage neighbours", curve, n, rounds)
+            assert torch.equal(o5[keep], v_def[keep]) and torch.equal(f5[keep], vf_def[keep]), ("garbage neighbours mirror", curve, n, rounds)
             o3, f3 = eng.double_scalarmul_t(curve, torch.zeros_like(k1), k2, bad, validate=True)
             rej = f1 == 2
             assert torch.equal(f3 == 2, rej) and torch.equal(o3[~rej], o1[~rej]) and not bool(o3[rej].any()), ("validate dsm", curve, n, rounds)
