@@ -99,22 +99,70 @@ WORKLOADS = {
     "p521r1_var_2^19": ("p521r1", "var", 1 << 19, 330, _var_unsat(18, 0, 66, 0, 780, 17 * 17, mont=False)),
     "bls12_381_g1_var_2^20": ("bls12_381_g1", "var", 1 << 20, 224, _var_unsat(14, 14, 32, 1, 570, 2 * 12 * 12)),
 }
-# HBM bytes per launch measured with rocprofv3 PMC passes (tools/profile.sh; summaries under
-# profiles/): FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for 16-byte-per-lane
-# reads on gfx950, plus WRITE_SIZE, summed over the kernels of one step.  Counters cannot be
-# read from inside this process, so the figure is the committed measurement of this very
-# workload, not a live one; null where no profile has been taken.
-MEASURED_TRAFFIC = {
-    "p256r1_var_2^20": {"bytes": 2 * (6786535305 + 109929528) + 3698666166 + 70295648,
-                        "fetch_raw": 6786535305 + 109929528, "write": 3698666166 + 70295648,
-                        "source": "profiles/r01_p256r1_var_u29.json"},
-    "ed25519_base_2^20": {"bytes": 2 * (1135026666 + 108984009) + 118721354 + 70266038,
-                          "fetch_raw": 1135026666 + 108984009, "write": 118721354 + 70266038,
-                          "source": "profiles/r01_ed25519_base.json"},
-    "x25519_2^20": {"bytes": 2 * (31830262 + 106681508) + 118489737 + 36701348,
-                    "fetch_raw": 31830262 + 106681508, "write": 118489737 + 36701348,
-                    "source": "profiles/r01_x25519.json"},
+# HBM bytes per launch measured with rocprofv3 PMC passes (tools/profile_all.sh -> tools/prof_summary.py;
+# summaries committed under profiles/): FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for
+# 16-byte-per-lane reads on gfx950, plus WRITE_SIZE, summed over the kernels of one step.  Counters
+# cannot be read from inside this process, so `roofline.traffic` is loaded from the committed summary
+# of this very workload (named in traffic_detail.source); null when that file is absent.
+PROFILE_ROUND = "r02"
+# kernels of one step per workload op: substrings of the kernel names in the summary
+STEP_KERNELS = {
+    ("var", "default"): ["k_scalarmul_var_unsat<eccx::{U}, false>", "k_batch_to_affine_unsat<eccx::{U}, 1,"],
+    ("var", "glv"): ["k_scalarmul_glv_unsat<eccx::{U}>", "k_batch_to_affine_unsat<eccx::{U}, 1,"],
+    ("var", "mirror"): ["k_scalarmul_var_mirror_unsat<eccx::{U}>", "k_batch_to_affine<eccx::{S}, 0,"],
+    ("var", "ct"): ["k_scalarmul_var_mirror_unsat<eccx::{U}>", "k_batch_to_affine<eccx::{S}, 0,"],
+    ("dsm", "default"): ["k_scalarmul_var_unsat<eccx::{U}, true>", "k_batch_to_affine_unsat<eccx::{U}, 1,"],
+    ("base", "default"): ["k_scalarmul_base_unsat<eccx::{U}>", "k_batch_to_affine_unsat<eccx::{U}, 1,"],
+    ("x25519", "default"): ["k_x25519_ladder_unsat<eccx::ED25519U>", "k_batch_to_affine_unsat<eccx::ED25519U, 3,"],
 }
+ED_STEP_KERNELS = {
+    ("var", "default"): ["k_ed_scalarmul_var_unsat<eccx::ED25519U, false>", "k_batch_to_affine_unsat<eccx::ED25519U, 2,"],
+    ("dsm", "default"): ["k_ed_scalarmul_var_unsat<eccx::ED25519U, true>", "k_batch_to_affine_unsat<eccx::ED25519U, 2,"],
+    ("base", "default"): ["k_ed_scalarmul_base_unsat<eccx::ED25519U>", "k_batch_to_affine_unsat<eccx::ED25519U, 2,"],
+    ("base", "lds"): ["k_ed_scalarmul_base_lds6<eccx::ED25519U>", "k_batch_to_affine_unsat<eccx::ED25519U, 2,"],
+}
+CURVE_STRUCTS = {"p256r1": ("P256", "P256U"), "p384r1": ("P384", "P384U"), "p521r1": ("P521", "P521U"),
+                 "bls12_381_g1": ("BLS12_381", "BLS12_381U"), "ed25519": ("ED25519", "ED25519U")}
+
+
+def profile_path(workload, variant):
+    tag = PROFILE_ROUND + "_" + workload.replace("^", "")
+    if variant != "default":
+        tag += "_" + variant
+    return os.path.join("profiles", tag + ".json")
+
+
+def measured_traffic(workload, curve, op, variant):
+    """HBM bytes of one step from the committed rocprofv3 PMC summary of this workload: for each
+    kernel of the step, the (kernel, grid) entry with the most dispatches (the timed launches),
+    FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE.  None if there is no summary."""
+    rel = profile_path(workload, variant)
+    path = os.path.join(ROOT, rel)
+    table = ED_STEP_KERNELS if curve == "ed25519" and op != "x25519" else STEP_KERNELS
+    pats = table.get((op, variant))
+    if not os.path.exists(path) or not pats:
+        return None
+    with open(path) as f:
+        prof = json.load(f)
+    S, U = CURVE_STRUCTS[curve]
+    fetch = write = 0.0
+    used = []
+    for pat in pats:
+        pat = pat.format(S=S, U=U)
+        best = None
+        for key, v in prof.get("pmc", {}).items():
+            if pat in key and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                rank = (v["FETCH_SIZE"]["dispatches"], v["hbm_read_bytes_per_dispatch_raw"])
+                if best is None or rank > best[0]:
+                    best = (rank, key, v)
+        if best is None:
+            return None
+        fetch += best[2]["hbm_read_bytes_per_dispatch_raw"]
+        write += best[2]["hbm_write_bytes_per_dispatch"]
+        used.append(best[1])
+    return {"bytes": int(2 * fetch + write), "fetch_raw": int(fetch), "write": int(write), "source": rel, "kernels": used}
+
+
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # Integer-multiplier issue costs measured by tools/ubench/valu_rates.hip on MI355X
 # (profiles/r01_valu_rates.jsonl): cycles one SIMD needs to issue the instruction for one
@@ -126,6 +174,59 @@ SIMDS = 256 * 4
 CLOCK_HZ = 2.4e9
 
 
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(ora, curve, op, args, n, ks, ks2, pts):
+    """The oracle (C restatement of the reference algorithm: RCB complete formulas, fixed 4-bit
+    window, 64-bit-limb Montgomery with unsigned __int128 -- kind "port") timed on this box's host
+    cores, in the shape SURVEY.md §8(d) asks for: the first 1024 units of the batch (BASELINE.json
+    configs[0]) on ONE thread and on ALL host cores, with nproc, the CPU model and ns per
+    operation; plus a larger sample on all cores, which is the `value` reported (1024 units over
+    hundreds of threads mostly measures thread start-up).  The authentic number would be the
+    reference's own `cargo bench -- <curve>::point::scalar_mul` (benches/curves.rs:247-265):
+    unavailable, there is no Rust toolchain on the box."""
+    nproc = os.cpu_count() or 1
+
+    def timed(m, threads):
+        c_k = ks[:m].cpu().numpy().tobytes()
+        c_p = pts[:m].cpu().numpy().tobytes() if op in ("var", "x25519", "dsm") else None
+        c_k2 = ks2[:m].cpu().numpy().tobytes() if op == "dsm" else None
+        t1 = time.perf_counter()
+        if op == "var":
+            ora.var(curve, c_k, c_p, threads=threads)
+        elif op == "dsm":   # the two scalar multiplications dominate; the final addition is not timed
+            ora.base(curve, c_k, threads=threads)
+            ora.var(curve, c_k2, c_p, threads=threads)
+        elif op == "x25519":
+            ora.x25519(c_k, c_p, threads=threads)
+        else:
+            ora.base(curve, c_k, threads=threads)
+        dt = time.perf_counter() - t1
+        return {"units": m, "threads": threads, "seconds": dt, "ops_per_s": m / dt, "ns_per_op": dt / m * 1e9}
+
+    small = min(n, 1024)
+    one = timed(small, 1)
+    allc = timed(small, nproc)
+    big_m = min(n, args.cpu_sample)
+    big = timed(big_m, nproc)
+    return {"value": big["ops_per_s"], "unit": "scalarmuls/s", "cores": nproc, "kind": "port",
+            "sample": f"first {big_m} units of the same {args.workload} batch, oracle/eccx_oracle.c (C restatement of the "
+                      f"reference algorithm), {nproc} threads, {big['seconds']:.2f} s",
+            "nproc": nproc, "cpu_model": _cpu_model(),
+            "n1024_1thread": one, "n1024_allcores": allc, "large_allcores": big,
+            "reference_cargo_bench": "unavailable (no Rust toolchain / crates.io on the box; "
+                                     "would be benches/curves.rs:247-265)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,11 +235,17 @@ def main():
     ap.add_argument("--workload", default="p256r1_var_2^20", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1 << 17)
-    ap.add_argument("--variant", default="default", choices=["default", "mirror", "lds", "l2"],
+    ap.add_argument("--variant", default="default", choices=["default", "mirror", "lds", "l2", "ct", "glv"],
                     help="default: fast kernels; mirror: reference-mirroring kernels; "
                          "lds: ed25519 fixed base with a signed 6-bit comb table resident in LDS; "
-                         "l2: the reference's 4-bit comb read through L2")
+                         "l2: the reference's 4-bit comb read through L2; "
+                         "ct: ECCX_CT_SCAN (mirror kernels, every table entry read); "
+                         "glv: ECCX_ASSUME_SUBGROUP (bls12_381_g1 endomorphism ladder)")
     args = ap.parse_args()
+    # ECCX_FORCE_DIST=1: initialise RCCL and run the gather pipeline even at world size 1, so that a
+    # one-GPU box exercises process-group init, the asynchronous gather on RCCL's stream and its
+    # ordering against the engine's kernels
+    force_dist = os.environ.get("ECCX_FORCE_DIST", "0") == "1"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # launched by hand without torch.distributed.run: start the ranks as a child job
@@ -160,13 +267,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank if use_dist else 0)
     curve, op, n, alg_bytes, mult = WORKLOADS[args.workload]
     fb, sb = E.field_bytes(curve), E.scalar_bytes(curve)
     eng = E.Engine(dev.index)
@@ -192,20 +301,27 @@ def main():
     outs = [torch.empty((n, out_cols), dtype=torch.uint8, device=dev) for _ in range(2)]
     flagss = [torch.empty((n,), dtype=torch.uint8, device=dev) for _ in range(2)]
     stream = torch.cuda.current_stream(dev)
-    pipe = GatherPipeline(n, out_cols, dev, slots=2)
+    pipe = GatherPipeline(n, out_cols, dev, slots=2, force=force_dist)
 
     mirror = args.variant == "mirror"
+    ct = args.variant == "ct"
+    glv = args.variant == "glv"
+    # one-time costs out of the timed region (and out of the _dev calls): tables + scratch
+    if op in ("base", "dsm"):
+        eng.prepare(curve, base=True, base_lds=args.variant == "lds")
+    eng.reserve(curve, n, var=op in ("var", "dsm"), mirror=mirror or ct)
 
     def step(slot):
         out, flags = outs[slot], flagss[slot]
         if op == "var":
-            eng.scalarmul_var_t(curve, ks, pts, out, flags, stream=stream.cuda_stream, mirror=mirror)
+            eng.scalarmul_var_t(curve, ks, pts, out, flags, stream=stream.cuda_stream, mirror=mirror, ct_scan=ct,
+                                assume_subgroup=glv)
         elif op == "dsm":
             eng.double_scalarmul_t(curve, ks, ks2, pts, out, flags, stream=stream.cuda_stream)
         elif op == "x25519":
             eng.x25519_t(ks, pts, out, flags, stream=stream.cuda_stream)
         else:
-            eng.scalarmul_base_t(curve, ks, out, flags, stream=stream.cuda_stream, mirror=mirror,
+            eng.scalarmul_base_t(curve, ks, out, flags, stream=stream.cuda_stream, mirror=mirror, ct_scan=ct,
                                  table_in_lds={"lds": True, "l2": False}.get(args.variant))
 
     def run(steps, events=None):
@@ -228,13 +344,13 @@ def main():
 
     # kernel-only time of the dominant kernel, HIP events on the launch stream
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     run(args.steps, ev)
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
@@ -242,59 +358,71 @@ def main():
     last = (args.steps - 1) & 1
     out, flags = outs[last], flagss[last]
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
 
-    # correctness gate on the timed buffers: sampled comparison with the oracle (rank 0)
+    # correctness gate on the timed buffers: sampled comparison with the oracle (rank 0).  With a
+    # gather (N > 1 or ECCX_FORCE_DIST) the bytes checked are the ones that ARRIVED on the root:
+    # rank 0's own slice and one peer's slice of the gathered buffer, the peer's inputs regenerated
+    # from its seeds.
     parity = None
     cpu = None
     if rank == 0:
         from tests import oracle_lib
 
         ora = oracle_lib.load()
-        idx = torch.randperm(n, generator=torch.Generator().manual_seed(1))[:256].sort().values.to(dev)
-        s_k = ks[idx].cpu().numpy().tobytes()
-        if op == "var":
-            w_out, w_inf, _ = ora.var(curve, s_k, pts[idx].cpu().numpy().tobytes(), threads=8)
-        elif op == "dsm":
-            # u1*G and u2*Q from the C oracle, their sum with textbook affine arithmetic
-            from oracle import ecc_ref as R
 
-            c = R.CURVES[curve]
-            a_out, a_inf, _ = ora.base(curve, s_k, threads=8)
-            b_out, b_inf, _ = ora.var(curve, ks2[idx].cpu().numpy().tobytes(), pts[idx].cpu().numpy().tobytes(), threads=8)
-            pb = 2 * fb
-            dec = lambda buf, fl, i: None if fl[i] else (int.from_bytes(buf[i * pb:i * pb + fb], "big"),
-                                                         int.from_bytes(buf[i * pb + fb:(i + 1) * pb], "big"))
-            sums = [R.affine_add(c, dec(a_out, a_inf, i), dec(b_out, b_inf, i)) for i in range(len(a_inf))]
-            w_out = b"".join(bytes(pb) if t is None else t[0].to_bytes(fb, "big") + t[1].to_bytes(fb, "big") for t in sums)
-            w_inf = bytes(1 if t is None else 0 for t in sums)
-        elif op == "x25519":
-            w_out, w_inf = ora.x25519(s_k, pts[idx].cpu().numpy().tobytes(), threads=8)
-        else:
-            w_out, w_inf, _ = ora.base(curve, s_k, threads=8)
-        parity = (out[idx].cpu().numpy().tobytes() == w_out) and (flags[idx].cpu().numpy().tobytes() == w_inf)
-        if not args.no_cpu_baseline:
-            cores = min(16, os.cpu_count() or 1)
-            m = min(n, args.cpu_sample)
-            c_k = ks[:m].cpu().numpy().tobytes()
-            c_p = pts[:m].cpu().numpy().tobytes() if op in ("var", "x25519", "dsm") else None
-            t1 = time.perf_counter()
+        def expected(s_k, s_k2, s_pts):
             if op == "var":
-                ora.var(curve, c_k, c_p, threads=cores)
-            elif op == "dsm":   # the two scalar multiplications dominate; the final addition is not timed
-                ora.base(curve, c_k, threads=cores)
-                ora.var(curve, ks2[:m].cpu().numpy().tobytes(), c_p, threads=cores)
+                w_out, w_inf, _ = ora.var(curve, s_k, s_pts, threads=8)
+            elif op == "dsm":
+                # u1*G and u2*Q from the C oracle, their sum with textbook affine arithmetic
+                from oracle import ecc_ref as R
+
+                c = R.CURVES[curve]
+                a_out, a_inf, _ = ora.base(curve, s_k, threads=8)
+                b_out, b_inf, _ = ora.var(curve, s_k2, s_pts, threads=8)
+                pb = 2 * fb
+                le = curve == "ed25519"
+                order = "little" if le else "big"
+                dec = lambda buf, fl, i: None if (fl[i] and not le) else (int.from_bytes(buf[i * pb:i * pb + fb], order),
+                                                                         int.from_bytes(buf[i * pb + fb:(i + 1) * pb], order))
+                sums = [R.affine_add(c, dec(a_out, a_inf, i), dec(b_out, b_inf, i)) for i in range(len(a_inf))]
+                w_out = b"".join(bytes(pb) if t is None else t[0].to_bytes(fb, order) + t[1].to_bytes(fb, order) for t in sums)
+                w_inf = bytes(1 if t is None else 0 for t in sums)
             elif op == "x25519":
-                ora.x25519(c_k, c_p, threads=cores)
+                w_out, w_inf = ora.x25519(s_k, s_pts, threads=8)
             else:
-                ora.base(curve, c_k, threads=cores)
-            dt = time.perf_counter() - t1
-            cpu = {"value": m / dt, "unit": "scalarmuls/s", "cores": cores, "kind": "port",
-                   "sample": f"first {m} units of the same {args.workload} batch, oracle/eccx_oracle.c "
-                             f"(C restatement of the reference algorithm), {cores} threads, {dt:.2f} s"}
+                w_out, w_inf, _ = ora.base(curve, s_k, threads=8)
+            return w_out, w_inf
+
+        idx_cpu = torch.randperm(n, generator=torch.Generator().manual_seed(1))[:256].sort().values
+        idx = idx_cpu.to(dev)
+        g_out, g_flags = pipe.result(last)      # the gathered buffers on the root (the local ones without a gather)
+        w_out, w_inf = expected(ks[idx].cpu().numpy().tobytes(),
+                                ks2[idx].cpu().numpy().tobytes() if ks2 is not None else None,
+                                pts[idx].cpu().numpy().tobytes() if pts is not None else None)
+        parity = (g_out[idx].cpu().numpy().tobytes() == w_out) and (g_flags[idx].cpu().numpy().tobytes() == w_inf)
+        parity = parity and (out[idx].cpu().numpy().tobytes() == w_out)
+        if world > 1:
+            peer = world - 1
+            sel = idx_cpu.numpy()
+            p_k = W.random_scalars(curve, n, seed=10 + peer)[sel].tobytes()
+            p_r = W.random_scalars(curve, n, seed=1000 + peer)[sel].tobytes()
+            p_k2 = W.random_scalars(curve, n, seed=2000 + peer)[sel].tobytes() if op == "dsm" else None
+            if op in ("var", "dsm"):
+                p_pts = ora.base(curve, p_r, threads=8)[0]
+            elif op == "x25519":
+                p_pts = ora.x25519(p_r, None, threads=8)[0]
+            else:
+                p_pts = None
+            pw_out, pw_inf = expected(p_k, p_k2, p_pts)
+            pidx = idx + peer * n
+            parity = parity and (g_out[pidx].cpu().numpy().tobytes() == pw_out) and (g_flags[pidx].cpu().numpy().tobytes() == pw_inf)
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(ora, curve, op, args, n, ks, ks2, pts)
 
     if rank == 0:
         total_units = n * world * args.steps
@@ -305,6 +433,7 @@ def main():
         issue_cycles = mult["mad"] * CYC_MAD + mult["pair"] * CYC_PAIR
         valu_frac = (n / 64) * issue_cycles / (kernel_ms * 1e-3 * SIMDS * CLOCK_HZ)
         mul_rate = (mult["mad"] + mult["pair"]) * n / (kernel_ms * 1e-3)
+        traffic = measured_traffic(args.workload, curve, op, args.variant)
         line = {
             "metric": "variable-base scalarmuls/sec (batch) per GPU + achieved HBM GB/s vs roofline"
             if op == "var" else ("double-scalar u1*G + u2*Q /sec (batch) per GPU + achieved HBM GB/s vs roofline" if op == "dsm" else ("X25519 scalarmuls/sec (batch) per GPU + achieved HBM GB/s vs roofline" if op == "x25519"
@@ -325,9 +454,8 @@ def main():
                        "gather": "rccl gather to rank 0, overlapped with the next batch (all complete inside the timed region)" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS,
-                         "traffic": (MEASURED_TRAFFIC[args.workload]["bytes"]
-                                     if args.workload in MEASURED_TRAFFIC and args.variant == "default" else None),
-                         "traffic_detail": MEASURED_TRAFFIC.get(args.workload) if args.variant == "default" else None,
+                         "traffic": traffic["bytes"] if traffic else None,
+                         "traffic_detail": traffic,
                          "kernel_ms": kernel_ms, "alg_bytes_per_unit": alg_bytes,
                          "alg_bytes_per_launch": alg_bytes * n,
                          "note": "integer-VALU bound path, see valu; traffic above the algorithmic bytes is "
@@ -343,10 +471,18 @@ def main():
             "cpu_baseline": cpu,
             "parity_sample_ok": parity,
         }
+        if force_dist:
+            line["config"]["gather"] = "rccl gather forced at world size 1 (ECCX_FORCE_DIST)"
+        if not parity:
+            # a fast wrong answer is not a result: no value, non-zero exit
+            line["value"] = None
+            line["invalid"] = "sampled results differ from the oracle"
         print(json.dumps(line), flush=True)
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
+    if rank == 0 and not parity:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

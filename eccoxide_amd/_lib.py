@@ -22,6 +22,9 @@ SYMBOLS = {
     "eccx_shutdown": (None, [c_void_p]),
     "eccx_last_error": (c_char_p, [c_void_p]),
     "eccx_strerror": (c_char_p, [c_int]),
+    "eccx_prepare": (c_int, [c_void_p, c_int, c_uint32]),
+    "eccx_reserve": (c_int, [c_void_p, c_int, c_size_t, c_uint32]),
+    "eccx_device_bytes": (c_size_t, [c_void_p]),
     "eccx_scalarmul_var": (c_int, [c_void_p, c_int, c_size_t, _u8p, _u8p, _u8p, _u8p, _u8p, c_uint32]),
     "eccx_scalarmul_base": (c_int, [c_void_p, c_int, c_size_t, _u8p, _u8p, _u8p, _u8p, c_uint32]),
     "eccx_scalarmul_var_dev": (c_int, [c_void_p, c_int, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p]),

@@ -28,6 +28,7 @@ constexpr uint32_t K_OUT_TABLE = 1u << 1;
 constexpr uint32_t K_VALIDATE = 1u << 2;
 constexpr uint32_t K_OUT_ROWS = 1u << 3;
 constexpr uint32_t K_NEGATE_B = 1u << 5;  // second operand negated: a - b, u1*G - u2*Q
+constexpr uint32_t K_CT_SCAN = 1u << 6;   // table lookups scan every entry (ECCX_CT_SCAN)
 
 const CurveOps* ops_of(int curve) {
   switch (curve) {
@@ -56,7 +57,13 @@ struct eccx_ctx {
   uint32_t* jac = nullptr;  // un-normalised results of the fast kernels
   size_t jac_words = 0;
   std::mutex scratch_mu;
+  size_t table_bytes = 0;  // fixed-base tables owned by the context (eccx_device_bytes)
+  std::mutex err_mu;       // err is written by whichever host thread's call failed last
   std::string err;
+  void set_err(std::string m) {
+    std::lock_guard<std::mutex> g(err_mu);
+    err = std::move(m);
+  }
 };
 
 namespace {
@@ -65,7 +72,7 @@ namespace {
   do {                                                                                         \
     hipError_t e_ = (call);                                                                    \
     if (e_ != hipSuccess) {                                                                    \
-      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                          \
+      (ctx)->set_err(std::string(#call) + ": " + hipGetErrorString(e_));                       \
       return e_ == hipErrorOutOfMemory ? ECCX_ERR_NOMEM : ECCX_ERR_HIP;                        \
     }                                                                                          \
   } while (0)
@@ -208,9 +215,14 @@ struct DevMem {
   }
 };
 
-int ensure_comb(eccx_ctx* ctx, int curve, const CurveOps* ops) {
+// `caller`: the stream the call that needs the table was made on.  The build runs on the context's
+// own stream and uses the context's scratch slab and row buffer, which an earlier call still
+// running on `caller` may be using: the build is ordered after it (it blocks the host anyway --
+// eccx_prepare pays it up front).
+int ensure_comb(eccx_ctx* ctx, int curve, const CurveOps* ops, hipStream_t caller) {
   std::lock_guard<std::mutex> g(ctx->comb_mu);
   if (ctx->comb[curve]) return ECCX_OK;
+  HIP_TRY(ctx, hipStreamSynchronize(caller));
   int nw = 2 * ops->info.sb;
   size_t rows = (size_t)nw * 16;
   std::vector<uint8_t> k = comb_scalars(ops);
@@ -261,14 +273,20 @@ int ensure_comb(eccx_ctx* ctx, int curve, const CurveOps* ops) {
   if (d_utab) mem.release(d_utab);
   ctx->comb[curve] = d_tab;
   ctx->comb_u[curve] = d_utab;
+  ctx->table_bytes += rows * ops->info.table_words * sizeof(uint32_t);
+  if (d_utab) {
+    const int W = ops->comb_bits;
+    ctx->table_bytes += ((size_t)((8 * ops->info.sb + W - 1) / W) << W) * (size_t)ops->utable_words * sizeof(uint32_t);
+  }
   return ECCX_OK;
 }
 
 // table image of the LDS-resident fixed-base variant: entry (w, d) = d * 2^(bits*w) * G for the
 // digits 0 .. 2^(bits-1), built like the wide tables by the engine's own variable-base path
-int ensure_comb_lds(eccx_ctx* ctx, int curve, const CurveOps* ops) {
+int ensure_comb_lds(eccx_ctx* ctx, int curve, const CurveOps* ops, hipStream_t caller) {
   std::lock_guard<std::mutex> g(ctx->comb_mu);
   if (ctx->comb_lds[curve]) return ECCX_OK;
+  HIP_TRY(ctx, hipStreamSynchronize(caller));  // as ensure_comb
   const int sbytes = ops->info.sb;
   const size_t entries = (size_t)ops->lds_windows * ops->lds_digits, pb = 2 * (size_t)ops->info.fb;
   std::vector<uint8_t> k(entries * sbytes, 0);
@@ -298,6 +316,7 @@ int ensure_comb_lds(eccx_ctx* ctx, int curve, const CurveOps* ops) {
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   mem.release(d_tab);
   ctx->comb_lds[curve] = d_tab;
+  ctx->table_bytes += entries * (size_t)ops->lds_entry_words * sizeof(uint32_t);
   return ECCX_OK;
 }
 
@@ -328,7 +347,7 @@ int run_host(eccx_ctx* ctx, int curve, bool base, size_t n, const uint8_t* scala
   do {                                              \
     hipError_t e_ = (call);                         \
     if (e_ != hipSuccess) {                         \
-      ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); \
+      ctx->set_err(std::string(#call) + ": " + hipGetErrorString(e_)); \
       cleanup();                                    \
       return e_ == hipErrorOutOfMemory ? ECCX_ERR_NOMEM : ECCX_ERR_HIP; \
     }                                               \
@@ -370,7 +389,7 @@ int run_host(eccx_ctx* ctx, int curve, bool base, size_t n, const uint8_t* scala
   do {                                              \
     hipError_t e_ = (call);                         \
     if (e_ != hipSuccess) {                         \
-      ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); \
+      ctx->set_err(std::string(#call) + ": " + hipGetErrorString(e_)); \
       cleanup_all();                                \
       return e_ == hipErrorOutOfMemory ? ECCX_ERR_NOMEM : ECCX_ERR_HIP; \
     }                                               \
@@ -491,7 +510,15 @@ void eccx_shutdown(eccx_ctx* ctx) {
   delete ctx;
 }
 
-const char* eccx_last_error(const eccx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+const char* eccx_last_error(const eccx_ctx* ctx) {
+  if (!ctx) return "null context";
+  // a copy per calling thread: the string another thread's failing call replaces is never handed out
+  static thread_local std::string copy;
+  eccx_ctx* c = const_cast<eccx_ctx*>(ctx);
+  std::lock_guard<std::mutex> g(c->err_mu);
+  copy = c->err;
+  return copy.c_str();
+}
 
 const char* eccx_strerror(int code) {
   switch (code) {
@@ -504,6 +531,49 @@ const char* eccx_strerror(int code) {
   }
 }
 
+int eccx_prepare(eccx_ctx* ctx, int curve, uint32_t what) {
+  const CurveOps* ops = ops_of(curve);
+  if (!ctx) return ECCX_ERR_ARG;
+  if (!ops) return ECCX_ERR_CURVE;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = ECCX_OK;
+  if (what & ECCX_PREP_BASE) rc = ensure_comb(ctx, curve, ops, ctx->stream);
+  if (!rc && (what & ECCX_PREP_BASE_LDS)) {
+    if (!ops->base_lds || !ops->lds_convert) return ECCX_ERR_ARG;
+    rc = ensure_comb_lds(ctx, curve, ops, ctx->stream);
+  }
+  return rc;
+}
+
+int eccx_reserve(eccx_ctx* ctx, int curve, size_t max_n, uint32_t what) {
+  const CurveOps* ops = ops_of(curve);
+  if (!ctx) return ECCX_ERR_ARG;
+  if (!ops) return ECCX_ERR_CURVE;
+  if (max_n == 0) return ECCX_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_rows(ctx, ops, max_n);  // every entry point writes un-normalised rows first
+  if (rc) return rc;
+  if (what & ECCX_PREP_VAR) {  // window-table slab of the default ladder (also the fused double-scalar kernel)
+    const int grid = ops->var_fast_grid ? ops->var_fast_grid(ctx->cus, max_n) : grid_for(ctx, max_n);
+    rc = ensure_scratch(ctx, ops->info.row5_words, grid);
+    if (rc) return rc;
+  }
+  if ((what & ECCX_PREP_MIRROR) && ops->info.row_words) {  // slab of the reference-mirroring ladder
+    const int grid = ops->var_grid ? ops->var_grid(ctx->cus, max_n) : grid_for(ctx, max_n);
+    rc = ensure_scratch(ctx, ops->info.row_words, grid);
+    if (rc) return rc;
+  }
+  return ECCX_OK;
+}
+
+size_t eccx_device_bytes(const eccx_ctx* ctx) {
+  if (!ctx) return 0;
+  eccx_ctx* c = const_cast<eccx_ctx*>(ctx);
+  std::lock_guard<std::mutex> g1(c->comb_mu);
+  std::lock_guard<std::mutex> g2(c->scratch_mu);
+  return c->table_bytes + (c->scratch_words + c->jac_words) * sizeof(uint32_t);
+}
+
 int eccx_scalarmul_var_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_scalars, const void* d_points,
                            void* d_out, void* d_flags, void* d_proj, uint32_t opts, void* stream) {
   const CurveOps* ops = ops_of(curve);
@@ -513,9 +583,12 @@ int eccx_scalarmul_var_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_sca
   if (!d_scalars || !d_points || !d_out || !d_flags) return ECCX_ERR_ARG;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = static_cast<hipStream_t>(stream);  // NULL = HIP's default stream
+  // ECCX_CT_SCAN: the reference-mirroring ladder (complete formulas, no data-dependent branch) with
+  // select_from_table's full scan; edwards25519's mirror ladder is bit-serial and has no table
+  const bool ct = (opts & ECCX_CT_SCAN) != 0;
   return launch_var(ctx, ops, n, static_cast<const uint8_t*>(d_scalars), static_cast<const uint8_t*>(d_points),
                     static_cast<uint8_t*>(d_out), static_cast<uint8_t*>(d_flags), static_cast<uint8_t*>(d_proj),
-                    kopts_of(opts), (opts & ECCX_MIRROR_REFERENCE) != 0, s);
+                    kopts_of(opts) | (ct ? K_CT_SCAN : 0u), ct || (opts & ECCX_MIRROR_REFERENCE) != 0, s);
 }
 
 int eccx_scalarmul_base_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_scalars, void* d_out, void* d_flags,
@@ -525,16 +598,16 @@ int eccx_scalarmul_base_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_sc
   if (!ops) return ECCX_ERR_CURVE;
   if (n == 0) return ECCX_OK;
   if (!d_scalars || !d_out || !d_flags) return ECCX_ERR_ARG;
-  (void)opts;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  int rc = ensure_comb(ctx, curve, ops);
-  if (rc) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);  // NULL = HIP's default stream
+  int rc = ensure_comb(ctx, curve, ops, s);
+  if (rc) return rc;
   size_t need = (n + eccx::LAUNCH_WG - 1) / eccx::LAUNCH_WG;
   int grid = (int)std::max<size_t>(1, std::min(need, (size_t)ctx->cus * 8));
   // default: 16-bit windows over the engine's own wide table (the 4-bit comb of the reference's
   // layout stays reachable through ECCX_MIRROR_REFERENCE / ECCX_TABLE_IN_LDS / ECCX_TABLE_IN_L2)
-  if (!d_proj && !(opts & (ECCX_MIRROR_REFERENCE | ECCX_TABLE_IN_LDS | ECCX_TABLE_IN_L2)) && ops->base_unsat &&
+  const uint32_t ct = (opts & ECCX_CT_SCAN) ? K_CT_SCAN : 0u;  // reference-layout 4-bit comb, every entry read
+  if (!d_proj && !(opts & (ECCX_MIRROR_REFERENCE | ECCX_TABLE_IN_LDS | ECCX_TABLE_IN_L2 | ECCX_CT_SCAN)) && ops->base_unsat &&
       ctx->comb_u[curve]) {
     rc = ensure_rows(ctx, ops, n);
     if (rc) return rc;
@@ -547,8 +620,8 @@ int eccx_scalarmul_base_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_sc
   }
   // LDS-resident table (ECCX_TABLE_IN_LDS, edwards25519): signed 6-bit windows, the widest table
   // that fits 160 KiB
-  if (!d_proj && (opts & ECCX_TABLE_IN_LDS) && ops->base_lds && ops->lds_convert && ops->to_affine_var) {
-    rc = ensure_comb_lds(ctx, curve, ops);
+  if (!d_proj && !ct && (opts & ECCX_TABLE_IN_LDS) && ops->base_lds && ops->lds_convert && ops->to_affine_var) {
+    rc = ensure_comb_lds(ctx, curve, ops, s);
     if (rc) return rc;
     rc = ensure_rows(ctx, ops, n);
     if (rc) return rc;
@@ -563,14 +636,14 @@ int eccx_scalarmul_base_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_sc
     if (rc) return rc;
     HIP_TRY(ctx, ops->base(grid, s, n, static_cast<const uint8_t*>(d_scalars), ctx->comb[curve],
                            reinterpret_cast<uint8_t*>(ctx->jac), static_cast<uint8_t*>(d_flags), nullptr,
-                           K_OUT_ROWS));
+                           K_OUT_ROWS | ct));
     HIP_TRY(ctx, ops->to_affine_hom(norm_grid(ctx, n), s, n, ctx->jac, static_cast<uint8_t*>(d_out),
                                     static_cast<uint8_t*>(d_flags)));
     return ECCX_OK;
   }
   HIP_TRY(ctx, ops->base(grid, s, n, static_cast<const uint8_t*>(d_scalars), ctx->comb[curve],
                          static_cast<uint8_t*>(d_out), static_cast<uint8_t*>(d_flags),
-                         static_cast<uint8_t*>(d_proj), 0u));
+                         static_cast<uint8_t*>(d_proj), ct));
   return ECCX_OK;
 }
 
@@ -752,12 +825,13 @@ int eccx_double_scalarmul_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_
   if (n == 0) return ECCX_OK;
   if (!d_u1 || !d_u2 || !d_q || !d_out || !d_flags) return ECCX_ERR_ARG;
   if (!ops->var_fused || !ops->to_affine_var) return ECCX_ERR_ARG;
+  if (opts & ECCX_CT_SCAN) return ECCX_ERR_ARG;  // the verify shape works on public data; no scanning form
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   // one kernel: the ladder for u2*Q, then the 16-bit comb of u1*G onto the same point
-  int rc = ensure_comb(ctx, curve, ops);
+  hipStream_t s = static_cast<hipStream_t>(stream);  // NULL = HIP's default stream
+  int rc = ensure_comb(ctx, curve, ops, s);
   if (rc) return rc;
   if (!ctx->comb_u[curve]) return ECCX_ERR_HIP;
-  hipStream_t s = static_cast<hipStream_t>(stream);  // NULL = HIP's default stream
   const int grid = ops->var_fast_grid ? ops->var_fast_grid(ctx->cus, n) : grid_for(ctx, n);
   rc = ensure_scratch(ctx, ops->info.row5_words, grid);
   if (rc) return rc;
@@ -834,7 +908,7 @@ int eccx_x25519(eccx_ctx* ctx, size_t n, const uint8_t* scalars, const uint8_t* 
     if (d_f) (void)hipFree(d_f);
   };
   auto fail = [&](hipError_t e, const char* what) {
-    ctx->err = std::string(what) + ": " + hipGetErrorString(e);
+    ctx->set_err(std::string(what) + ": " + hipGetErrorString(e));
     cleanup();
     return e == hipErrorOutOfMemory ? ECCX_ERR_NOMEM : ECCX_ERR_HIP;
   };

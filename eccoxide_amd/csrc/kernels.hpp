@@ -23,6 +23,9 @@ enum : uint32_t {
   OPT_VALIDATE = 1u << 2,           // reject non-canonical / off-curve input points (flag 2)
   OPT_OUT_ROWS = 1u << 3,           // write the un-normalised result as a row of Montgomery limbs
                                     // (X, Y, Z) for k_batch_to_affine instead of normalising here
+  OPT_CT_SCAN = 1u << 6,            // table lookups read EVERY entry and keep the wanted one with selects
+                                    // (select_from_table, projective.rs:427-434 / curve25519.rs:862-869):
+                                    // no memory address and no branch depends on a scalar digit
 };
 
 constexpr int WG = 256;
@@ -147,11 +150,29 @@ __global__ void __launch_bounds__(WG) k_scalarmul_base(size_t n, const uint8_t* 
     uint32_t byte = k[SB - 1 - (w >> 1)];
     uint32_t d = (w & 1) ? (byte >> 4) : (byte & 0x0f);  // low nibble first (projective.rs:974-976)
     Pt<C> sel;
-    const uint32_t* __restrict__ e = table + ((size_t)w * 16 + d) * (2 * L);
+    if (opts & OPT_CT_SCAN) {
+      // select_from_table (projective.rs:427-434): every entry of the window is read (the address
+      // is the same for all lanes) and kept under a per-lane select; digit 0 keeps (0 : 1 : 0)
+      pt_set_inf<C>(sel);
+      Fe<L> one;
+      fe_set<C>(one, C::ONE);
+      for (uint32_t j = 1; j < 16; ++j) {
+        const uint32_t* __restrict__ e = table + ((size_t)w * 16 + j) * (2 * L);
+        Fe<L> ex, ey;
 #pragma unroll
-    for (int i = 0; i < L; ++i) { sel.x.v[i] = e[i]; sel.y.v[i] = e[L + i]; }
-    fe_set<C>(sel.z, C::ONE);
-    if (d == 0) pt_set_inf<C>(sel);
+        for (int i = 0; i < L; ++i) { ex.v[i] = e[i]; ey.v[i] = e[L + i]; }
+        const bool take = (j == d);
+        fe_select<C>(sel.x, take, ex, sel.x);
+        fe_select<C>(sel.y, take, ey, sel.y);
+        fe_select<C>(sel.z, take, one, sel.z);
+      }
+    } else {
+      const uint32_t* __restrict__ e = table + ((size_t)w * 16 + d) * (2 * L);
+#pragma unroll
+      for (int i = 0; i < L; ++i) { sel.x.v[i] = e[i]; sel.y.v[i] = e[L + i]; }
+      fe_set<C>(sel.z, C::ONE);
+      if (d == 0) pt_set_inf<C>(sel);
+    }
     pt_add<C>(q, q, sel);
   }
   if (active) store_result<C>(idx, q, false, out, flags, proj, opts);
@@ -278,6 +299,25 @@ __global__ void __launch_bounds__(WG) k_ed_scalarmul_base(size_t n, const uint8_
     uint32_t byte = k[31 - (w >> 1)];  // indexes the big-endian scalar (curve25519.rs:842-846)
     uint32_t d = (w & 1) ? (byte >> 4) : (byte & 0x0f);
     EdPt<C> sel;
+    if (opts & OPT_CT_SCAN) {
+      // select_from_table (curve25519.rs:862-869): read all 16 entries, keep one by select; the
+      // general addition (Point::add) follows, as in the reference
+      ed_set_identity<C>(sel);
+      Fe<L> one;
+      fe_set<C>(one, C::ONE);
+      for (uint32_t j = 1; j < 16; ++j) {
+        const uint32_t* __restrict__ ej = table + ((size_t)w * 16 + j) * (4 * L);
+        Fe<L> ex, ey, et;
+#pragma unroll
+        for (int i = 0; i < L; ++i) { ex.v[i] = ej[i]; ey.v[i] = ej[L + i]; et.v[i] = ej[2 * L + i]; }
+        const bool take = (j == d);
+        fe_select<C>(sel.x, take, ex, sel.x);
+        fe_select<C>(sel.y, take, ey, sel.y);
+        fe_select<C>(sel.t, take, et, sel.t);
+      }
+      ed_add<C>(q, q, sel);
+      continue;
+    }
     const uint32_t* __restrict__ e = table + ((size_t)w * 16 + d) * (4 * L);
 #pragma unroll
     for (int i = 0; i < L; ++i) { sel.x.v[i] = e[i]; sel.y.v[i] = e[L + i]; }

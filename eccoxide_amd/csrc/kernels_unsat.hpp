@@ -1096,7 +1096,21 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_var_mir
           e = (win & 1) ? (byte & 0x0f) : (byte >> 4);  // high nibble first (projective.rs:885)
         }
         UPt<CU> sel, t;
-        upt_load<CU>(sel, row(e));
+        if (!building && (opts & OPT_CT_SCAN)) {
+          // select_from_table (projective.rs:427-434): every row of the lane's table is read and
+          // the wanted one kept by select -- no address depends on the digit
+          upt_load<CU>(sel, row(0));
+          for (uint32_t j = 1; j < 16; ++j) {
+            UPt<CU> c;
+            upt_load<CU>(c, row(j));
+            const bool take = (j == e);
+            u_select(sel.x, take, c.x, sel.x);
+            u_select(sel.y, take, c.y, sel.y);
+            u_select(sel.z, take, c.z, sel.z);
+          }
+        } else {
+          upt_load<CU>(sel, row(e));
+        }
         upt_add<CU>(t, q, sel);
         q = t;
       }

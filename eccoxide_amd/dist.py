@@ -64,14 +64,18 @@ class GatherPipeline:
     `result(slot)` returns (out, flags) views on the root, (None, None) elsewhere.
     """
 
-    def __init__(self, shard_rows: int, out_cols: int, device, slots: int = 2, root: int = 0, group=None):
+    def __init__(self, shard_rows: int, out_cols: int, device, slots: int = 2, root: int = 0, group=None,
+                 force: bool = False):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.root, self.group, self.rows = root, group, shard_rows
         self.pending = [[] for _ in range(slots)]
         self.local = [None] * slots
         self.out = self.flags = None
-        if self.world > 1 and self.rank == root:
+        # force: run the collective even in a group of one (bench.py ECCX_FORCE_DIST: one GPU
+        # exercising the RCCL path -- communicator, gather on its own stream, stream ordering)
+        self.active = self.world > 1 or (force and dist.is_initialized())
+        if self.active and self.rank == root:
             self.out = [torch.empty((self.world * shard_rows, out_cols), dtype=torch.uint8, device=device)
                         for _ in range(slots)]
             self.flags = [torch.empty((self.world * shard_rows,), dtype=torch.uint8, device=device)
@@ -80,7 +84,7 @@ class GatherPipeline:
     def start(self, slot: int, out: torch.Tensor, flags: torch.Tensor) -> None:
         assert not self.pending[slot], "slot still in flight: call finish(slot) first"
         self.local[slot] = (out, flags)
-        if self.world == 1:
+        if not self.active:
             return
         for src, dst in ((out, self.out), (flags, self.flags)):
             bufs = list(dst[slot].split(self.rows, dim=0)) if self.rank == self.root else None
@@ -92,11 +96,22 @@ class GatherPipeline:
         self.pending[slot] = []
 
     def result(self, slot: int):
-        if self.world == 1:
+        if not self.active:
             return self.local[slot]
         if self.rank != self.root:
             return None, None
         return self.out[slot], self.flags[slot]
+
+
+def engine_compute(engine, curve, **opts):
+    """The per-rank compute of sharded_scalarmul for an Engine (or anything with its device-tensor
+    API): variable base when a points shard is given, fixed base otherwise.  Shards are slices of
+    the global tensors, so they are made contiguous before their addresses reach the C ABI."""
+    def compute(scalars, points):
+        if points is None:
+            return engine.scalarmul_base_t(curve, scalars.contiguous(), **opts)
+        return engine.scalarmul_var_t(curve, scalars.contiguous(), points.contiguous(), **opts)
+    return compute
 
 
 def sharded_scalarmul(compute: Callable[[torch.Tensor, Optional[torch.Tensor]], Tuple[torch.Tensor, torch.Tensor]],

@@ -21,6 +21,9 @@ X25519_RAW_LADDER = 1 << 4
 SUBTRACT = 1 << 5
 CHECK_SUBGROUP = 1 << 6
 UNCOMPRESSED = 1 << 7
+CT_SCAN = 1 << 8
+ASSUME_SUBGROUP = 1 << 9
+PREP_VAR, PREP_BASE, PREP_BASE_LDS, PREP_MIRROR = 1, 2, 4, 8
 FLAG_FINITE, FLAG_INFINITY, FLAG_REJECTED = 0, 1, 2
 
 
@@ -88,11 +91,51 @@ class Engine:
         if rc != 0:
             raise EccxError(rc, self._lib.eccx_last_error(self._ctx).decode())
 
+    def _tensors(self, n: int, *specs):
+        """Validate the device tensors of a `_t` call before their raw addresses reach a kernel:
+        each spec is (name, tensor or None, bytes per unit).  Every tensor must be a contiguous
+        torch.uint8 CUDA tensor ON THIS ENGINE'S GPU holding exactly n units -- a short or foreign
+        buffer would otherwise be an out-of-bounds or cross-device access inside the kernel."""
+        import torch
+
+        for name, t, width in specs:
+            if t is None:
+                continue
+            if not (getattr(t, "is_cuda", False) and t.dtype == torch.uint8 and t.is_contiguous()):
+                raise ValueError(f"{name}: tensors must be contiguous torch.uint8 CUDA tensors")
+            if t.device.index != self.device:
+                raise ValueError(f"{name}: tensor lives on cuda:{t.device.index}, this engine is bound to cuda:{self.device}")
+            if t.numel() != n * width:
+                raise ValueError(f"{name}: expected {n} x {width} bytes, got {t.numel()}")
+
+    @staticmethod
+    def _units(t, width: int, name: str) -> int:
+        if t.numel() % width:
+            raise ValueError(f"{name}: {t.numel()} bytes is not a multiple of the {width}-byte unit")
+        return t.numel() // width
+
+    # ---- one-time costs ------------------------------------------------------
+    def prepare(self, curve, *, base: bool = True, base_lds: bool = False):
+        """eccx_prepare: build the fixed-base tables of `curve` now (blocking)."""
+        self._check(self._lib.eccx_prepare(self._ctx, curve_id(curve),
+                                           (PREP_BASE if base else 0) | (PREP_BASE_LDS if base_lds else 0)))
+
+    def reserve(self, curve, max_n: int, *, var: bool = True, mirror: bool = False):
+        """eccx_reserve: size the scratch slab and row buffer for batches of up to max_n units."""
+        self._check(self._lib.eccx_reserve(self._ctx, curve_id(curve), int(max_n),
+                                           (PREP_VAR if var else 0) | (PREP_MIRROR if mirror else 0)))
+
+    def device_bytes(self) -> int:
+        return int(self._lib.eccx_device_bytes(self._ctx))
+
     # ---- host buffers ------------------------------------------------------
     def scalarmul_var(self, curve, scalars: bytes, points: bytes, *, validate: bool = False,
-                      want_proj: bool = False, mirror: bool = False):
+                      want_proj: bool = False, mirror: bool = False, ct_scan: bool = False,
+                      assume_subgroup: bool = False):
         """out[i] = scalars[i] * points[i]; returns (affine bytes, flags[, proj bytes]).
-        mirror=True (implied by want_proj) runs the reference-mirroring kernels."""
+        mirror=True (implied by want_proj) runs the reference-mirroring kernels; ct_scan=True those
+        with the full-table scan (secret scalars); assume_subgroup=True (bls12_381_g1) the
+        endomorphism ladder for bases known to be in G1."""
         cid = curve_id(curve)
         sb, fb = scalar_bytes(cid), field_bytes(cid)
         if len(scalars) % sb:
@@ -104,14 +147,17 @@ class Engine:
         flags = ctypes.create_string_buffer(max(1, n))
         proj = ctypes.create_string_buffer(max(1, n * _proj_width(cid))) if want_proj else None
         rc = self._lib.eccx_scalarmul_var(self._ctx, cid, n, scalars, points, out, flags, proj,
-                                          (VALIDATE_POINTS if validate else 0) | (MIRROR_REFERENCE if mirror else 0))
+                                          (VALIDATE_POINTS if validate else 0) | (MIRROR_REFERENCE if mirror else 0)
+                                          | (CT_SCAN if ct_scan else 0) | (ASSUME_SUBGROUP if assume_subgroup else 0))
         self._check(rc)
         res = (out.raw[: n * 2 * fb], flags.raw[:n])
         return res + (proj.raw[: n * _proj_width(cid)],) if want_proj else res
 
-    def scalarmul_base(self, curve, scalars: bytes, *, want_proj: bool = False, mirror: bool = False):
+    def scalarmul_base(self, curve, scalars: bytes, *, want_proj: bool = False, mirror: bool = False,
+                       ct_scan: bool = False):
         """out[i] = scalars[i] * G via the fixed-base comb table.
-        mirror=True (implied by want_proj) runs the reference-mirroring kernels."""
+        mirror=True (implied by want_proj) runs the reference-mirroring kernels; ct_scan=True the
+        reference's 4-bit comb with the full-table scan (secret scalars)."""
         cid = curve_id(curve)
         sb, fb = scalar_bytes(cid), field_bytes(cid)
         if len(scalars) % sb:
@@ -121,7 +167,7 @@ class Engine:
         flags = ctypes.create_string_buffer(max(1, n))
         proj = ctypes.create_string_buffer(max(1, n * _proj_width(cid))) if want_proj else None
         rc = self._lib.eccx_scalarmul_base(self._ctx, cid, n, scalars, out, flags, proj,
-                                           MIRROR_REFERENCE if mirror else 0)
+                                           (MIRROR_REFERENCE if mirror else 0) | (CT_SCAN if ct_scan else 0))
         self._check(rc)
         res = (out.raw[: n * 2 * fb], flags.raw[:n])
         return res + (proj.raw[: n * _proj_width(cid)],) if want_proj else res
@@ -200,16 +246,12 @@ class Engine:
         cid = curve_id(curve)
         fb = field_bytes(cid)
         eb = 2 * fb if uncompressed else self.compressed_bytes(cid)
-        n = enc.numel() // eb
+        n = self._units(enc, eb, "enc")
         if out is None:
             out = torch.empty((n, 2 * fb), dtype=torch.uint8, device=enc.device)
         if flags is None:
             flags = torch.empty((n,), dtype=torch.uint8, device=enc.device)
-        for t in (enc, out, flags):
-            if not (t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()):
-                raise ValueError("tensors must be contiguous torch.uint8 CUDA tensors")
-        if enc.numel() != n * eb or out.numel() != n * 2 * fb or flags.numel() != n:
-            raise ValueError("enc, out and flags must describe the same number of units")
+        self._tensors(n, ("enc", enc, eb), ("out", out, 2 * fb), ("flags", flags, 1))
         if stream is None:
             stream = torch.cuda.current_stream(enc.device).cuda_stream
         self._check(self._lib.eccx_point_decompress_dev(self._ctx, cid, n, enc.data_ptr(), out.data_ptr(), flags.data_ptr(),
@@ -224,14 +266,10 @@ class Engine:
         cid = curve_id(curve)
         fb = field_bytes(cid)
         eb = 2 * fb if uncompressed else self.compressed_bytes(cid)
-        n = xy.numel() // (2 * fb)
+        n = self._units(xy, 2 * fb, "xy")
         if out is None:
             out = torch.empty((n, eb), dtype=torch.uint8, device=xy.device)
-        for t in (xy, out) + ((inf,) if inf is not None else ()):
-            if not (t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()):
-                raise ValueError("tensors must be contiguous torch.uint8 CUDA tensors")
-        if xy.numel() != n * 2 * fb or out.numel() != n * eb or (inf is not None and inf.numel() != n):
-            raise ValueError("xy, inf and out must describe the same number of units")
+        self._tensors(n, ("xy", xy, 2 * fb), ("inf", inf, 1), ("out", out, eb))
         if stream is None:
             stream = torch.cuda.current_stream(xy.device).cuda_stream
         self._check(self._lib.eccx_point_compress_dev(self._ctx, cid, n, xy.data_ptr(),
@@ -260,16 +298,13 @@ class Engine:
 
         cid = curve_id(curve)
         fb = field_bytes(cid)
-        n = a.numel() // (2 * fb)
+        n = self._units(a, 2 * fb, "a")
         if out is None:
             out = torch.empty((n, 2 * fb), dtype=torch.uint8, device=a.device)
         if flags is None:
             flags = torch.empty((n,), dtype=torch.uint8, device=a.device)
-        for t in (a, b, out, flags) + tuple(x for x in (a_inf, b_inf) if x is not None):
-            if not (t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()):
-                raise ValueError("tensors must be contiguous torch.uint8 CUDA tensors")
-        if a.numel() != n * 2 * fb or b.numel() != n * 2 * fb or any(x is not None and x.numel() != n for x in (a_inf, b_inf)):
-            raise ValueError("a, b and the infinity flags must describe the same number of units")
+        self._tensors(n, ("a", a, 2 * fb), ("b", b, 2 * fb), ("a_inf", a_inf, 1), ("b_inf", b_inf, 1),
+                      ("out", out, 2 * fb), ("flags", flags, 1))
         if stream is None:
             stream = torch.cuda.current_stream(a.device).cuda_stream
         rc = self._lib.eccx_point_add_dev(self._ctx, cid, n, a.data_ptr(), a_inf.data_ptr() if a_inf is not None else None,
@@ -286,16 +321,12 @@ class Engine:
 
         cid = curve_id(curve)
         fb, sb = field_bytes(cid), scalar_bytes(cid)
-        n = u1.numel() // sb
+        n = self._units(u1, sb, "u1")
         if out is None:
             out = torch.empty((n, 2 * fb), dtype=torch.uint8, device=u1.device)
         if flags is None:
             flags = torch.empty((n,), dtype=torch.uint8, device=u1.device)
-        for t in (u1, u2, q, out, flags):
-            if not (t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()):
-                raise ValueError("tensors must be contiguous torch.uint8 CUDA tensors")
-        if u2.numel() != n * sb or q.numel() != n * 2 * fb:
-            raise ValueError("u1, u2 and q must describe the same number of units")
+        self._tensors(n, ("u1", u1, sb), ("u2", u2, sb), ("q", q, 2 * fb), ("out", out, 2 * fb), ("flags", flags, 1))
         if stream is None:
             stream = torch.cuda.current_stream(u1.device).cuda_stream
         rc = self._lib.eccx_double_scalarmul_dev(self._ctx, cid, n, u1.data_ptr(), u2.data_ptr(), q.data_ptr(),
@@ -309,14 +340,12 @@ class Engine:
         """Device-tensor form of x25519 (torch.uint8 CUDA tensors, n x 32)."""
         import torch
 
-        n = scalars.numel() // 32
+        n = self._units(scalars, 32, "scalars")
         if out is None:
             out = torch.empty((n, 32), dtype=torch.uint8, device=scalars.device)
         if flags is None:
             flags = torch.empty((n,), dtype=torch.uint8, device=scalars.device)
-        for t in (scalars, out, flags) + ((u,) if u is not None else ()):
-            if not (t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()):
-                raise ValueError("tensors must be contiguous torch.uint8 CUDA tensors")
+        self._tensors(n, ("scalars", scalars, 32), ("u", u, 32), ("out", out, 32), ("flags", flags, 1))
         if stream is None:
             stream = torch.cuda.current_stream(scalars.device).cuda_stream
         rc = self._lib.eccx_x25519_dev(self._ctx, n, scalars.data_ptr(), u.data_ptr() if u is not None else None,
@@ -334,51 +363,53 @@ class Engine:
 
     # ---- device tensors (torch.uint8, resident on this engine's GPU) -----------
     def scalarmul_var_t(self, curve, scalars, points, out=None, flags=None, proj=None, *,
-                        validate: bool = False, mirror: bool = False, stream: Optional[int] = None):
+                        validate: bool = False, mirror: bool = False, ct_scan: bool = False,
+                        assume_subgroup: bool = False, stream: Optional[int] = None):
         """Device-resident variant: tensors are torch.uint8 CUDA tensors; the launch is
         enqueued on `stream` (raw hipStream_t handle; default: torch's current stream)."""
         import torch
 
         cid = curve_id(curve)
         sb, fb = scalar_bytes(cid), field_bytes(cid)
-        n = scalars.numel() // sb
+        n = self._units(scalars, sb, "scalars")
         if out is None:
             out = torch.empty((n, 2 * fb), dtype=torch.uint8, device=scalars.device)
         if flags is None:
             flags = torch.empty((n,), dtype=torch.uint8, device=scalars.device)
-        for t in (scalars, points, out, flags) + ((proj,) if proj is not None else ()):
-            if not (t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()):
-                raise ValueError("tensors must be contiguous torch.uint8 CUDA tensors")
+        self._tensors(n, ("scalars", scalars, sb), ("points", points, 2 * fb), ("out", out, 2 * fb), ("flags", flags, 1),
+                      ("proj", proj, _proj_width(cid)))
+        if points is None:
+            raise ValueError("points: required")
         if stream is None:
             stream = torch.cuda.current_stream(scalars.device).cuda_stream
         rc = self._lib.eccx_scalarmul_var_dev(self._ctx, cid, n, scalars.data_ptr(), points.data_ptr(),
                                               out.data_ptr(), flags.data_ptr(),
                                               proj.data_ptr() if proj is not None else None,
-                                              (VALIDATE_POINTS if validate else 0) | (MIRROR_REFERENCE if mirror else 0),
+                                              (VALIDATE_POINTS if validate else 0) | (MIRROR_REFERENCE if mirror else 0)
+                                              | (CT_SCAN if ct_scan else 0) | (ASSUME_SUBGROUP if assume_subgroup else 0),
                                               stream)
         self._check(rc)
         return out, flags
 
     def scalarmul_base_t(self, curve, scalars, out=None, flags=None, proj=None, *, stream: Optional[int] = None,
-                         table_in_lds: Optional[bool] = None, mirror: bool = False):
+                         table_in_lds: Optional[bool] = None, mirror: bool = False, ct_scan: bool = False):
         import torch
 
         cid = curve_id(curve)
         sb, fb = scalar_bytes(cid), field_bytes(cid)
-        n = scalars.numel() // sb
+        n = self._units(scalars, sb, "scalars")
         if out is None:
             out = torch.empty((n, 2 * fb), dtype=torch.uint8, device=scalars.device)
         if flags is None:
             flags = torch.empty((n,), dtype=torch.uint8, device=scalars.device)
-        for t in (scalars, out, flags) + ((proj,) if proj is not None else ()):
-            if not (t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()):
-                raise ValueError("tensors must be contiguous torch.uint8 CUDA tensors")
+        self._tensors(n, ("scalars", scalars, sb), ("out", out, 2 * fb), ("flags", flags, 1),
+                      ("proj", proj, _proj_width(cid)))
         if stream is None:
             stream = torch.cuda.current_stream(scalars.device).cuda_stream
         rc = self._lib.eccx_scalarmul_base_dev(self._ctx, cid, n, scalars.data_ptr(), out.data_ptr(),
                                                flags.data_ptr(), proj.data_ptr() if proj is not None else None,
                                                (0 if table_in_lds is None else (TABLE_IN_LDS if table_in_lds else TABLE_IN_L2))
-                                               | (MIRROR_REFERENCE if mirror else 0),
+                                               | (MIRROR_REFERENCE if mirror else 0) | (CT_SCAN if ct_scan else 0),
                                                stream)
         self._check(rc)
         return out, flags

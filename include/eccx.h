@@ -40,11 +40,36 @@
  *     subgroup that equals (k mod n)*P.
  *
  * All functions return 0 on success or a negative ECCX_ERR_* code; none aborts.
- * A context is bound to one GPU and owns its device scratch (window-table slab, row buffer)
- * and the fixed-base tables it builds at first use (16-bit-window tables: 84-415 MB per curve
- * used, once).  Calls on ONE context must not overlap in time -- enqueue them on one stream,
- * or serialise them; use one context per stream / host thread for concurrency (table
- * construction is guarded by a mutex; the tables are read-only afterwards).
+ *
+ * SIDE CHANNELS -- read before using this for secret scalars.  The reference's Point * Scalar,
+ * mul_base and to_affine_ct are constant-time: select_from_table reads every table entry
+ * (projective.rs:427-434, curve25519.rs:862-869) and nothing branches on the scalar.  The DEFAULT
+ * kernels here (and ECCX_TABLE_IN_LDS / ECCX_TABLE_IN_L2) are NOT: they read their window and comb
+ * tables at addresses chosen by scalar digits and take wave-uniform branches on data-dependent
+ * ballots (accumulator at infinity, equal points).  They return the same bytes, and are meant for
+ * PUBLIC scalars (signature verification, public-key checks) or callers who accept that.  For
+ * secret scalars (key generation, signing, ECDH) pass ECCX_CT_SCAN: the reference-mirroring kernels
+ * with the full-table scan -- complete formulas, no digit-dependent address, no digit-dependent
+ * branch (the cost is in DESIGN.md section 3).  No timing measurements back either claim: GPU
+ * schedulers and caches are not modelled.  eccx_x25519 is uniform by construction (conditional
+ * swaps are selects, no table).
+ *
+ * MEMORY AND BLOCKING.  A context is bound to one GPU and owns
+ *   - the window-table slab of the variable-base ladders: resident lanes x 17 rows (P-256:
+ *     0.86 GB, P-384 / BLS12-381: 0.62 GB, P-521: 0.79 GB; sized by the largest batch seen),
+ *   - a buffer of un-normalised result rows, 112-224 bytes per unit of the largest batch seen,
+ *   - the fixed-base tables of each curve used: the 16-bit-window table (134 MB for p256r1,
+ *     ed25519 and bls12_381_g1, 201 MB p384r1, 415 MB p521r1), the reference-layout comb
+ *     (64-265 KB), and for ECCX_TABLE_IN_LDS a 155 KB image.
+ * eccx_device_bytes() reports the total.  The buffers grow on demand: a call with a batch larger
+ * than any before frees and reallocates them after a device-wide synchronisation, and the first
+ * fixed-base / double-scalar call per curve builds the tables (64-271 ms) after waiting for the
+ * caller's stream.  eccx_prepare() and eccx_reserve() pay both up front; after them the _dev entry
+ * points never block, allocate or free.
+ * Calls on ONE context must not overlap in time -- enqueue them on one stream, or serialise
+ * them; use one context per stream / host thread for concurrency (table construction is guarded
+ * by a mutex; the tables are read-only afterwards; eccx_last_error() hands each calling thread
+ * its own copy of the message).
  */
 #ifndef ECCX_H
 #define ECCX_H
@@ -96,7 +121,28 @@ enum {
   ECCX_X25519_RAW_LADDER = 1u << 4, /* eccx_x25519: raw MontgomeryPoint::scale_bytes semantics */
   ECCX_SUBTRACT = 1u << 5,         /* eccx_point_add: compute a - b */
   ECCX_CHECK_SUBGROUP = 1u << 6,   /* eccx_point_decompress, bls12_381_g1: reject points outside G1 */
-  ECCX_UNCOMPRESSED = 1u << 7      /* eccx_point_[de]compress, bls12_381_g1: the 96-byte zcash flavour */
+  ECCX_UNCOMPRESSED = 1u << 7,     /* eccx_point_[de]compress, bls12_381_g1: the 96-byte zcash flavour */
+  ECCX_CT_SCAN = 1u << 8,          /* eccx_scalarmul_var / _base: secret scalars.  Runs the reference-mirroring
+                                      kernels (complete RCB / unified Edwards formulas, fixed 4-bit
+                                      windows; edwards25519 variable base: the reference's bit-serial
+                                      double-and-add) with select_from_table's scan of all 16 entries
+                                      (src/curve/projective.rs:427-434, curve25519.rs:862-869): no memory
+                                      address and no branch depends on a scalar digit.  Same bytes out.
+                                      Not accepted by eccx_double_scalarmul (public data). */
+  ECCX_ASSUME_SUBGROUP = 1u << 9   /* eccx_scalarmul_var, bls12_381_g1: the caller guarantees every base point
+                                      is in the prime-order subgroup G1 (e.g. it was decoded under
+                                      ECCX_CHECK_SUBGROUP, or is a multiple of the generator).  The
+                                      ladder then splits k = k1 + k2*x^2 and uses the endomorphism
+                                      sigma(P) = [-x^2]P (src/curve/bls12_381/g1.rs:90-109): half the
+                                      doublings.  For a point outside G1 the result is NOT k*P. */
+};
+
+/* eccx_prepare / eccx_reserve: which one-time costs to pay now */
+enum {
+  ECCX_PREP_VAR = 1u << 0,      /* variable base and double-scalar, default kernels: window-table slab */
+  ECCX_PREP_BASE = 1u << 1,     /* fixed base and double-scalar: the comb tables of the curve */
+  ECCX_PREP_BASE_LDS = 1u << 2, /* ECCX_TABLE_IN_LDS image (edwards25519) */
+  ECCX_PREP_MIRROR = 1u << 3    /* ECCX_MIRROR_REFERENCE / ECCX_CT_SCAN / proj: slab of the mirror ladder */
 };
 
 /* flag values written per unit */
@@ -114,6 +160,17 @@ void eccx_shutdown(eccx_ctx* ctx);
 const char* eccx_last_error(const eccx_ctx* ctx);
 const char* eccx_strerror(int code);
 
+/* Pay the one-time costs of later calls now (both block until done):
+ *   eccx_prepare  builds the fixed-base tables `what` names for `curve`;
+ *   eccx_reserve  sizes the scratch slab and the row buffer for batches of up to max_n units of
+ *                 `curve` through the entry points `what` names (buffers only ever grow; reserve
+ *                 every curve you will use, the largest footprint wins).
+ * After both, a _dev call with n <= max_n returns without synchronising, allocating or freeing.
+ * eccx_device_bytes: device memory the context currently owns. */
+int eccx_prepare(eccx_ctx* ctx, int curve, uint32_t what);
+int eccx_reserve(eccx_ctx* ctx, int curve, size_t max_n, uint32_t what);
+size_t eccx_device_bytes(const eccx_ctx* ctx);
+
 /* Variable base: out[i] = scalars[i] * points[i].
  *   scalars : n x SB          points : n x 2FB (affine x||y)
  *   out     : n x 2FB         flags  : n bytes (ECCX_FLAG_*)
@@ -129,8 +186,10 @@ int eccx_scalarmul_base(eccx_ctx* ctx, int curve, size_t n, const uint8_t* scala
 
 /* Device-pointer forms: every buffer is device memory of ctx's GPU, the work is
  * enqueued on `stream` (a hipStream_t; NULL = HIP's default stream) and the call
- * returns without synchronising.  (The first fixed-base call per curve builds the comb
- * table on the context's own stream and waits for it.) */
+ * returns without synchronising -- except for the one-time costs listed under MEMORY AND
+ * BLOCKING above (first table build per curve: waits for `stream`, builds, blocks; a batch
+ * larger than any before: device-wide synchronisation + reallocation), which eccx_prepare /
+ * eccx_reserve move out of the way. */
 int eccx_scalarmul_var_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_scalars, const void* d_points,
                            void* d_out, void* d_flags, void* d_proj, uint32_t opts, void* stream);
 int eccx_scalarmul_base_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_scalars, void* d_out,

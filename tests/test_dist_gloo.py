@@ -1,7 +1,8 @@
 """The N>1 path (contiguous shards, no data-path collective, one gather to rank 0) with
 world_size 2 on the gloo backend.  The per-rank compute is the CPU oracle here (test
 infrastructure standing in for the GPU engine); what is under test is the sharding and
-gather logic of eccoxide_amd/dist.py.  CPU only."""
+gather logic of eccoxide_amd/dist.py.  CPU only.  (The same pipeline on RCCL with the real
+engine: tests/test_gpu_api.py.)"""
 import os
 import socket
 
@@ -123,6 +124,82 @@ def test_world2_gather_pipeline_overlaps_batches():
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [True, True]
+
+
+class OracleEngine:
+    """Stands in for eccoxide_amd.Engine on a box without a GPU: the same device-tensor API shape
+    (uint8 tensors in, (out, flags) tensors out), computed by the oracle.  Test infrastructure."""
+
+    def __init__(self, threads=2):
+        from tests import oracle_lib
+
+        self.ora, self.threads = oracle_lib.load(), threads
+
+    @staticmethod
+    def _t(buf, cols):
+        t = torch.frombuffer(bytearray(buf), dtype=torch.uint8) if len(buf) else torch.empty((0,), dtype=torch.uint8)
+        return t.reshape(-1, cols) if cols else t
+
+    def scalarmul_var_t(self, curve, scalars, points, out=None, flags=None, **_):
+        assert scalars.is_contiguous() and points.is_contiguous()
+        o, f, _p = self.ora.var(curve, scalars.numpy().tobytes(), points.numpy().tobytes(), threads=self.threads)
+        return self._t(o, points.shape[1]), self._t(f, 0)
+
+    def scalarmul_base_t(self, curve, scalars, out=None, flags=None, **_):
+        assert scalars.is_contiguous()
+        o, f, _p = self.ora.base(curve, scalars.numpy().tobytes(), threads=self.threads)
+        return self._t(o, 2 * self.ora.fb(curve)), self._t(f, 0)
+
+
+def _engine_api_worker(rank, world, port, n, curve, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from eccoxide_amd.dist import engine_compute, sharded_scalarmul
+
+        eng = OracleEngine()
+        ks = torch.from_numpy(W.random_scalars(curve, n, seed=21))
+        rs = torch.from_numpy(W.random_scalars(curve, n, seed=22))
+        # fixed base, sharded: every rank computes its slice of r_i * G, the root gets all of them
+        pts, pf = sharded_scalarmul(engine_compute(eng, curve), rs, None)
+        full_pts, full_pf = eng.scalarmul_base_t(curve, rs)
+        ok = True
+        if rank == 0:
+            ok &= torch.equal(pts, full_pts) and torch.equal(pf, full_pf)
+        # variable base, sharded, on the (replicated) bases
+        out, flags = sharded_scalarmul(engine_compute(eng, curve), ks, full_pts)
+        if rank == 0:
+            want_o, want_f = eng.scalarmul_var_t(curve, ks, full_pts)
+            ok &= torch.equal(out, want_o) and torch.equal(flags, want_f) and tuple(out.shape) == (n, full_pts.shape[1])
+        else:
+            ok &= out is None and flags is None
+        # gather=False: the rank keeps its own shard
+        mine, _ = sharded_scalarmul(engine_compute(eng, curve), ks, full_pts, gather=False)
+        lo, hi = W.shard_bounds(n, world, rank)
+        ok &= mine.shape[0] == hi - lo
+        q.put(bool(ok))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("curve,n", [("p256r1", 41), ("ed25519", 30)])
+def test_world2_sharded_through_the_engine_tensor_api(curve, n):
+    """sharded_scalarmul(engine_compute(engine, curve), ...) -- the call a multi-GPU host makes --
+    with an object of the Engine's tensor-API shape on every rank: fixed and variable base, ragged
+    and equal shards."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_engine_api_worker, args=(r, 2, port, n, curve, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(2)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

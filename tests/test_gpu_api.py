@@ -1,0 +1,290 @@
+"""GPU tests of the C ABI's behaviour around the kernels (round 2): one-time costs and their
+ordering against a busy stream, eccx_prepare / eccx_reserve, ECCX_CT_SCAN parity, the sharded entry
+points over two contexts, and the RCCL gather path on one GPU (ECCX_FORCE_DIST).  Results are still
+compared with the oracle bit for bit.
+"""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+from eccoxide_amd import workload as W
+from tests.oracle_lib import ROOT
+
+pytestmark = pytest.mark.gpu
+
+WEI = ["p256r1", "p384r1", "p521r1", "bls12_381_g1"]
+ALL = WEI + ["ed25519"]
+_SIZES = {"p256r1": (32, 32), "p384r1": (48, 48), "p521r1": (66, 66), "bls12_381_g1": (48, 32), "ed25519": (32, 32)}
+
+
+def _bases(oracle, curve, n, seed):
+    return oracle.base(curve, W.random_scalars(curve, n, seed=seed).tobytes(), threads=16)[0]
+
+
+# ---- ECCX_CT_SCAN: same bytes as the default kernels and the oracle -------------------------------
+@pytest.mark.parametrize("curve", ALL)
+def test_ct_scan_matches_oracle(engine, oracle, curve):
+    """The scanning lookup (select_from_table, projective.rs:427-434 / curve25519.rs:862-869) on the
+    reference-mirroring kernels: every digit value occurs in 600 random scalars, plus the edge
+    scalars 0, 1, order - 1 and one with every nibble zero but the top one."""
+    fb, sb = _SIZES[curve]
+    n = 600
+    ks = bytearray(W.random_scalars(curve, n, seed=901).tobytes())
+    order = W.order(curve)
+    edge = [0, 1, order - 1, 0xF << (8 * sb - 8), 0x10]
+    for i, v in enumerate(edge):
+        ks[i * sb:(i + 1) * sb] = (v % (1 << (8 * sb))).to_bytes(sb, "big")
+    ks = bytes(ks)
+    pts = _bases(oracle, curve, n, seed=902)
+    want = oracle.var(curve, ks, pts, threads=16)
+    got = engine.scalarmul_var(curve, ks, pts, ct_scan=True)
+    assert got[0] == want[0] and got[1] == want[1]
+    assert engine.scalarmul_var(curve, ks, pts) == got
+    want_b = oracle.base(curve, ks, threads=16)
+    got_b = engine.scalarmul_base(curve, ks, ct_scan=True)
+    assert got_b[0] == want_b[0] and got_b[1] == want_b[1]
+    assert engine.scalarmul_base(curve, ks) == got_b
+
+
+def test_ct_scan_is_refused_for_the_verify_shape(engine):
+    import eccoxide_amd as E
+
+    lib = engine._lib
+    z = ctypes.create_string_buffer(64)
+    rc = lib.eccx_double_scalarmul(engine._ctx, 0, 1, bytes(32), bytes(32), bytes(64), z, z, 1 << 8)
+    assert rc == -2
+    assert E.engine.CT_SCAN == 1 << 8
+
+
+# ---- the first table build must not disturb work still running on the caller's stream -------------
+def test_first_fixed_base_call_waits_for_the_callers_stream(oracle):
+    """a fresh context, an asynchronous 2^20 variable-base batch, then immediately the
+    first fixed-base call (which builds the comb tables with the context's scratch slab and row
+    buffer).  The ladder that was still running must come back intact."""
+    import torch
+
+    import eccoxide_amd as E
+
+    n = 1 << 20
+    ks = W.random_scalars("p256r1", n, seed=911)
+    with E.Engine(0) as boot:           # bases from another context: `eng` stays without tables
+        d_r = torch.from_numpy(W.random_scalars("p256r1", n, seed=912)).cuda()
+        pts, _ = boot.scalarmul_base_t("p256r1", d_r)
+        torch.cuda.synchronize()
+    d_k = torch.from_numpy(ks).cuda()
+    small = torch.from_numpy(W.random_scalars("p256r1", 512, seed=913)).cuda()
+    with E.Engine(0) as eng:
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            out, flags = eng.scalarmul_var_t("p256r1", d_k, pts, stream=s.cuda_stream)     # ~16 ms of GPU work
+            b_out, b_flags = eng.scalarmul_base_t("p256r1", small, stream=s.cuda_stream)   # first use: builds
+        torch.cuda.synchronize()
+        sample = np.random.Generator(np.random.PCG64(3)).choice(n, size=2048, replace=False)
+        sample.sort()
+        t = torch.from_numpy(sample).cuda()
+        want = oracle.var("p256r1", ks[sample].tobytes(), pts[t].cpu().numpy().tobytes(), threads=16)
+        assert out[t].cpu().numpy().tobytes() == want[0]
+        assert flags[t].cpu().numpy().tobytes() == want[1]
+        want_b = oracle.base("p256r1", small.cpu().numpy().tobytes(), threads=16)
+        assert b_out.cpu().numpy().tobytes() == want_b[0]
+        # and the whole batch again, now that nothing overlaps
+        out2, _ = eng.scalarmul_var_t("p256r1", d_k, pts)
+        torch.cuda.synchronize()
+        assert torch.equal(out, out2)
+
+
+# ---- eccx_prepare + eccx_reserve: afterwards a _dev call is only an enqueue -----------------------
+def test_prepared_dev_calls_do_not_wait_for_the_stream(oracle):
+    """After prepare + reserve, scalarmul_var_dev / scalarmul_base_dev / double_scalarmul_dev on a
+    stream that is busy for ~50 ms return in well under that (no synchronisation, allocation or
+    table build inside the call), the context's memory does not change, and the results are right."""
+    import torch
+
+    import eccoxide_amd as E
+
+    n = 1 << 18
+    with E.Engine(0) as eng:
+        assert eng.device_bytes() == 0
+        eng.prepare("p256r1", base=True)
+        eng.reserve("p256r1", n, var=True)
+        owned = eng.device_bytes()
+        assert owned > 134_000_000            # the 16-bit-window table alone
+        d_k = torch.from_numpy(W.random_scalars("p256r1", n, seed=921)).cuda()
+        d_r = torch.from_numpy(W.random_scalars("p256r1", n, seed=922)).cuda()
+        d_u = torch.from_numpy(W.random_scalars("p256r1", n, seed=923)).cuda()
+        out_b = torch.empty((n, 64), dtype=torch.uint8, device="cuda")
+        out_v = torch.empty((n, 64), dtype=torch.uint8, device="cuda")
+        out_d = torch.empty((n, 64), dtype=torch.uint8, device="cuda")
+        fl = [torch.empty((n,), dtype=torch.uint8, device="cuda") for _ in range(3)]
+        s = torch.cuda.Stream()
+        a = torch.randn(8192, 8192, device="cuda")
+        (a @ a).sum().item()                              # rocBLAS initialised outside the measurement
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s):
+            for _ in range(12):                           # >= 50 ms of work queued ahead on the stream
+                a = (a @ a) * 1e-4
+            t0 = time.perf_counter()
+            eng.scalarmul_base_t("p256r1", d_r, out_b, fl[0], stream=s.cuda_stream)
+            eng.scalarmul_var_t("p256r1", d_k, out_b, out_v, fl[1], stream=s.cuda_stream)
+            eng.double_scalarmul_t("p256r1", d_u, d_k, out_b, out_d, fl[2], stream=s.cuda_stream)
+            dt = time.perf_counter() - t0
+            busy = not s.query()
+        torch.cuda.synchronize()
+        assert busy, "the stream drained before the calls returned: the test did not test anything"
+        assert dt < 0.02, f"three prepared _dev calls took {dt * 1e3:.1f} ms on a busy stream"
+        assert eng.device_bytes() == owned
+        idx = torch.arange(0, n, 997, device="cuda")
+        s_r, s_k = d_r[idx].cpu().numpy().tobytes(), d_k[idx].cpu().numpy().tobytes()
+        want_b = oracle.base("p256r1", s_r, threads=16)
+        assert out_b[idx].cpu().numpy().tobytes() == want_b[0]
+        want_v = oracle.var("p256r1", s_k, want_b[0], threads=16)
+        assert out_v[idx].cpu().numpy().tobytes() == want_v[0]
+        # u*G + k*(r*G) = (u + k*r)*G
+        order = W.order("p256r1")
+        s_u = d_u[idx].cpu().numpy().tobytes()
+        m = len(idx)
+        comb = b"".join(((int.from_bytes(s_u[i * 32:(i + 1) * 32], "big")
+                          + int.from_bytes(s_k[i * 32:(i + 1) * 32], "big") * int.from_bytes(s_r[i * 32:(i + 1) * 32], "big")) % order
+                         ).to_bytes(32, "big") for i in range(m))
+        assert out_d[idx].cpu().numpy().tobytes() == oracle.base("p256r1", comb, threads=16)[0]
+
+
+def test_last_error_is_per_thread_copy(engine):
+    """eccx_last_error hands out a copy: the pointer stays valid whatever other threads do."""
+    import threading
+
+    lib = engine._lib
+    errs = []
+
+    def worker():
+        for _ in range(200):
+            errs.append(lib.eccx_last_error(engine._ctx))
+
+    ts = [threading.Thread(target=worker) for _ in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert all(isinstance(e, bytes) for e in errs)
+
+
+# ---- sharded entry points over two contexts (one GPU here; one per GPU on a node) -------------------
+@pytest.mark.parametrize("curve,n", [("p256r1", 1501), ("p384r1", 777), ("ed25519", 1023)])
+def test_sharded_entry_points_two_contexts_ragged(oracle, curve, n):
+    """eccx_scalarmul_{var,base}_sharded with two contexts on device 0 and a batch size that does
+    not divide: contiguous shards [n*g/2, n*(g+1)/2), one host thread per context, results land in
+    the caller's buffers in order."""
+    import eccoxide_amd as E
+
+    fb, sb = _SIZES[curve]
+    cid = E.curve_id(curve)
+    ks = W.random_scalars(curve, n, seed=931).tobytes()
+    pts = _bases(oracle, curve, n, seed=932)
+    want_v = oracle.var(curve, ks, pts, threads=16)
+    want_b = oracle.base(curve, ks, threads=16)
+    with E.Engine(0) as e1, E.Engine(0) as e2:
+        lib = e1._lib
+        arr = (ctypes.c_void_p * 2)(e1._ctx.value, e2._ctx.value)
+        out = ctypes.create_string_buffer(n * 2 * fb)
+        fl = ctypes.create_string_buffer(n)
+        assert lib.eccx_scalarmul_var_sharded(arr, 2, cid, n, ks, pts, out, fl, 0) == 0
+        assert out.raw == want_v[0] and fl.raw == want_v[1]
+        out = ctypes.create_string_buffer(n * 2 * fb)
+        fl = ctypes.create_string_buffer(n)
+        assert lib.eccx_scalarmul_base_sharded(arr, 2, cid, n, ks, out, fl, 0) == 0
+        assert out.raw == want_b[0] and fl.raw == want_b[1]
+        # n smaller than the number of contexts: one shard is empty
+        out = ctypes.create_string_buffer(2 * fb)
+        fl = ctypes.create_string_buffer(1)
+        assert lib.eccx_scalarmul_var_sharded(arr, 2, cid, 1, ks[:sb], pts[:2 * fb], out, fl, 0) == 0
+        assert out.raw == want_v[0][:2 * fb]
+
+
+# ---- the RCCL path on one GPU -----------------------------------------------------------------------
+def test_bench_with_forced_rccl_gather():
+    """ECCX_FORCE_DIST=1: bench.py initialises the nccl (= RCCL) process group at world size 1 and
+    runs GatherPipeline's asynchronous gathers on RCCL's stream, two batches in flight; the parity
+    sample is taken from the GATHERED buffers.  Proves communicator init, the gather and its
+    ordering against the engine's kernels on real hardware (an 8-GPU run adds the peers, not code)."""
+    env = dict(os.environ, ECCX_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577",
+               RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["parity_sample_ok"] is True
+    assert "forced" in line["config"]["gather"]
+    assert line["value"] > 1e7
+
+
+def test_gather_pipeline_on_rccl_world_of_one(oracle):
+    """GatherPipeline(force=True) inside this process: results of the engine's device-tensor API
+    gathered by RCCL into the root's contiguous area while the next batch computes."""
+    import torch
+    import torch.distributed as dist
+
+    import eccoxide_amd as E
+    from eccoxide_amd.dist import GatherPipeline
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29578")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        n = 1 << 14
+        dev = torch.device("cuda", 0)
+        with E.Engine(0) as eng:
+            ks = [torch.from_numpy(W.random_scalars("p256r1", n, seed=940 + i)).to(dev) for i in range(3)]
+            pts, _ = eng.scalarmul_base_t("p256r1", ks[0])
+            outs = [torch.empty((n, 64), dtype=torch.uint8, device=dev) for _ in range(2)]
+            fls = [torch.empty((n,), dtype=torch.uint8, device=dev) for _ in range(2)]
+            pipe = GatherPipeline(n, 64, dev, slots=2, force=True)
+            assert pipe.active
+            got = []
+            for i in range(3):
+                slot = i & 1
+                pipe.finish(slot)
+                if i >= 2:
+                    got.append(pipe.result(slot)[0].clone())
+                eng.scalarmul_var_t("p256r1", ks[i], pts, outs[slot], fls[slot])
+                pipe.start(slot, outs[slot], fls[slot])
+            pipe.finish(0)
+            pipe.finish(1)
+            torch.cuda.synchronize()
+            res = {0: got[0], 1: pipe.result(1)[0], 2: pipe.result(0)[0]}
+            for i in range(3):
+                want = oracle.var("p256r1", ks[i][:128].cpu().numpy().tobytes(), pts[:128].cpu().numpy().tobytes())[0]
+                assert res[i][:128].cpu().numpy().tobytes() == want, i
+                assert res[i].data_ptr() not in (outs[0].data_ptr(), outs[1].data_ptr())   # really the gathered copy
+            # the one-shot form a multi-GPU host calls, on the real engine
+            from eccoxide_amd.dist import engine_compute, sharded_scalarmul
+
+            o, f = sharded_scalarmul(engine_compute(eng, "p256r1"), ks[1], pts)
+            torch.cuda.synchronize()
+            assert torch.equal(o, res[1]) and int(f.max()) == 0
+    finally:
+        dist.destroy_process_group()
+
+
+# ---- BASELINE.json configs[2], literally: the table in LDS at the full batch ------------------------
+def test_full_size_ed25519_mul_base_table_in_lds(engine, oracle):
+    """Ed25519 mul_base with the comb table in LDS (ECCX_TABLE_IN_LDS) at batch 2^20: identical to
+    the default path on every unit, and to the oracle on a sample."""
+    import torch
+
+    n = 1 << 20
+    ks = W.random_scalars("ed25519", n, seed=2000)
+    d_k = torch.from_numpy(ks).cuda()
+    out, flags = engine.scalarmul_base_t("ed25519", d_k)
+    out_l, flags_l = engine.scalarmul_base_t("ed25519", d_k, table_in_lds=True)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out_l) and torch.equal(flags, flags_l)
+    sample = np.random.Generator(np.random.PCG64(7)).choice(n, size=1024, replace=False)
+    sample.sort()
+    want_out, want_inf, _ = oracle.base("ed25519", ks[sample].tobytes(), threads=16)
+    t = torch.from_numpy(sample).cuda()
+    assert out_l[t].cpu().numpy().tobytes() == want_out and flags_l[t].cpu().numpy().tobytes() == want_inf
