@@ -119,28 +119,6 @@ int norm_grid(const eccx_ctx* ctx, size_t n) {
   return (int)std::max<size_t>(1, std::min(tiles, (size_t)ctx->cus * 4));
 }
 
-// order r of bls12_381_g1, big-endian (src/params/bls12_381.rs ORDER_BYTES): the scalar of the
-// subgroup membership test [r]P = infinity
-const uint8_t BLS12_381_ORDER[32] = {0x73, 0xed, 0xa7, 0x53, 0x29, 0x9d, 0x7d, 0x48, 0x33, 0x39, 0xd8, 0x08, 0x09, 0xa1, 0xd8, 0x05,
-                                     0x53, 0xbd, 0xa4, 0x02, 0xff, 0xfe, 0x5b, 0xfe, 0xff, 0xff, 0xff, 0xff, 0x00, 0x00, 0x00, 0x01};
-
-// out[i] = row for every i (rows of 16 bytes or a multiple)
-__global__ void k_replicate_row(size_t n, int row_quads, const uint4* __restrict__ row, uint4* __restrict__ out) {
-  const size_t total = n * (size_t)row_quads;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
-    out[i] = row[i % row_quads];
-}
-// a decoded point whose multiple by the group order is not the point at infinity is rejected
-__global__ void k_reject_outside_subgroup(size_t n, const uint8_t* __restrict__ order_mul_flags, uint8_t* __restrict__ flags,
-                                          uint8_t* __restrict__ out, int point_bytes) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    if (flags[i] == 0 && order_mul_flags[i] == 0) {
-      flags[i] = 2;
-      for (int k = 0; k < point_bytes; ++k) out[i * (size_t)point_bytes + k] = 0;
-    }
-  }
-}
-
 int flat_grid(const eccx_ctx* ctx, size_t n) {
   size_t need = (n + eccx::LAUNCH_WG - 1) / eccx::LAUNCH_WG;
   return (int)std::max<size_t>(1, std::min(need, (size_t)ctx->cus * 8));
@@ -150,9 +128,21 @@ int flat_grid(const eccx_ctx* ctx, size_t n) {
 // un-normalised X:Y:Z available); otherwise the fast Jacobian kernel + batched
 // normalisation where the curve has one.
 int launch_var(eccx_ctx* ctx, const CurveOps* ops, size_t n, const uint8_t* d_scalars, const uint8_t* d_points,
-               uint8_t* d_out, uint8_t* d_flags, uint8_t* d_proj, uint32_t kopts, bool mirror, hipStream_t s) {
+               uint8_t* d_out, uint8_t* d_flags, uint8_t* d_proj, uint32_t kopts, bool mirror, hipStream_t s,
+               bool glv = false) {
   if (n == 0) return ECCX_OK;
   const bool fast = !mirror && ops->var_fast && !d_proj && !(kopts & K_OUT_TABLE);
+  if (fast && glv && ops->var_glv && d_points) {
+    // bases known to be in the prime-order subgroup: the endomorphism ladder (kernels_bls.hpp)
+    const int grid = ops->var_glv_grid(ctx->cus, n);
+    int rc = ensure_scratch(ctx, ops->glv_row_words, grid);
+    if (rc) return rc;
+    rc = ensure_rows(ctx, ops, n);
+    if (rc) return rc;
+    HIP_TRY(ctx, ops->var_glv(grid, s, n, d_scalars, d_points, ctx->jac, d_flags, ctx->scratch, kopts));
+    HIP_TRY(ctx, ops->to_affine_var(norm_grid(ctx, n), s, n, ctx->jac, d_out, d_flags));
+    return ECCX_OK;
+  }
   // persistent grid sized to the kernel's real residency (registers decide it)
   int grid = fast ? (ops->var_fast_grid ? ops->var_fast_grid(ctx->cus, n) : grid_for(ctx, n))
                   : (ops->var_grid ? ops->var_grid(ctx->cus, n) : grid_for(ctx, n));
@@ -557,6 +547,10 @@ int eccx_reserve(eccx_ctx* ctx, int curve, size_t max_n, uint32_t what) {
     const int grid = ops->var_fast_grid ? ops->var_fast_grid(ctx->cus, max_n) : grid_for(ctx, max_n);
     rc = ensure_scratch(ctx, ops->info.row5_words, grid);
     if (rc) return rc;
+    if (ops->var_glv) {  // ECCX_ASSUME_SUBGROUP: wider rows
+      rc = ensure_scratch(ctx, ops->glv_row_words, ops->var_glv_grid(ctx->cus, max_n));
+      if (rc) return rc;
+    }
   }
   if ((what & ECCX_PREP_MIRROR) && ops->info.row_words) {  // slab of the reference-mirroring ladder
     const int grid = ops->var_grid ? ops->var_grid(ctx->cus, max_n) : grid_for(ctx, max_n);
@@ -588,7 +582,8 @@ int eccx_scalarmul_var_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_sca
   const bool ct = (opts & ECCX_CT_SCAN) != 0;
   return launch_var(ctx, ops, n, static_cast<const uint8_t*>(d_scalars), static_cast<const uint8_t*>(d_points),
                     static_cast<uint8_t*>(d_out), static_cast<uint8_t*>(d_flags), static_cast<uint8_t*>(d_proj),
-                    kopts_of(opts) | (ct ? K_CT_SCAN : 0u), ct || (opts & ECCX_MIRROR_REFERENCE) != 0, s);
+                    kopts_of(opts) | (ct ? K_CT_SCAN : 0u), ct || (opts & ECCX_MIRROR_REFERENCE) != 0, s,
+                    (opts & ECCX_ASSUME_SUBGROUP) != 0);
 }
 
 int eccx_scalarmul_base_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_scalars, void* d_out, void* d_flags,
@@ -732,26 +727,10 @@ int eccx_point_decompress_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_
   } else {
     HIP_TRY(ctx, ops->decompress(flat_grid(ctx, n), s, n, static_cast<const uint8_t*>(d_enc), out, flags));
   }
-  if ((opts & ECCX_CHECK_SUBGROUP) && curve == ECCX_BLS12_381_G1) {
-    // [r]P through the variable-base kernel; rejected records hold (0, 0), whose multiple is
-    // some garbage the merge ignores
-    const size_t pb = 2 * (size_t)ops->info.fb;
-    DevMem mem;
-    uint8_t *d_k = nullptr, *d_row = nullptr, *d_mul = nullptr, *d_mul_flags = nullptr;
-    HIP_TRY(ctx, mem.alloc(&d_k, n * 32));
-    HIP_TRY(ctx, mem.alloc(&d_row, 32));
-    HIP_TRY(ctx, mem.alloc(&d_mul, n * pb));
-    HIP_TRY(ctx, mem.alloc(&d_mul_flags, n));
-    HIP_TRY(ctx, hipMemcpyAsync(d_row, BLS12_381_ORDER, 32, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_replicate_row, dim3(flat_grid(ctx, 2 * n)), dim3(eccx::LAUNCH_WG), 0, s, n, 2,
-                       reinterpret_cast<const uint4*>(d_row), reinterpret_cast<uint4*>(d_k));
-    HIP_TRY(ctx, hipGetLastError());
-    int rc = launch_var(ctx, ops, n, d_k, out, d_mul, d_mul_flags, nullptr, 0u, false, s);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_reject_outside_subgroup, dim3(flat_grid(ctx, n)), dim3(eccx::LAUNCH_WG), 0, s, n, d_mul_flags, flags,
-                       out, (int)pb);
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(s));  // the temporaries go away with this scope
+  if ((opts & ECCX_CHECK_SUBGROUP) && ops->subgroup_check) {
+    // the reference's endomorphism test sigma(P) == [-x^2]P (g1.rs:90-109), in place on the decoded
+    // points: no temporaries, no synchronisation
+    HIP_TRY(ctx, ops->subgroup_check(flat_grid(ctx, n), s, n, out, flags));
   }
   return ECCX_OK;
 }

@@ -287,6 +287,36 @@ def ref_add(c: WeierstrassParams, P: Proj, Q: Proj) -> Proj:
     return ref_add_am3(c, P, Q) if c.flavour == "am3" else ref_add_a0(c, P, Q)
 
 
+# ---- BLS12-381 G1 subgroup membership, the reference's endomorphism test ----------------------
+# src/curve/bls12_381/g1.rs:62-109; BETA: src/params/bls12_381.rs:100 (tests/golden/params.json "beta")
+BLS_X_ABS = 0xD201000000010000   # |x| of the (negative) seed
+BLS_BETA = 0x5F19672FDF76CE51BA69C6076A0F77EADDB3A93BE6F89688DE17D813620A00022E01FFFFFFFEFFFE
+
+
+def ref_g1_mul_by_abs_x(P: Proj) -> Proj:
+    """g1.rs:69-78: [|x|]P by double-and-add over the bits of |x| below the top one, complete formulas."""
+    c = BLS12_381_G1
+    acc = P
+    for i in range(62, -1, -1):
+        acc = ref_double_a0(c, acc)
+        if (BLS_X_ABS >> i) & 1:
+            acc = ref_add_a0(c, acc, P)
+    return acc
+
+
+def ref_g1_is_in_subgroup(P: Affine) -> bool:
+    """g1.rs:105-109: sigma(P) == -[x^2]P with sigma(x, y) = (beta x, y); projective equality as
+    is_equivalent (projective.rs:133-139).  The identity is in the subgroup."""
+    if P is None:
+        return True
+    c = BLS12_381_G1
+    p = c.p
+    Q = ref_g1_mul_by_abs_x(ref_g1_mul_by_abs_x((P[0], P[1], 1)))
+    mx, my, mz = Q[0], (-Q[1]) % p, Q[2]
+    sx, sy, sz = BLS_BETA * P[0] % p, P[1], 1
+    return (sx * mz - mx * sz) % p == 0 and (sy * mz - my * sz) % p == 0 and (mz % p != 0)
+
+
 def ref_double(c: WeierstrassParams, P: Proj) -> Proj:
     return ref_double_am3(c, P) if c.flavour == "am3" else ref_double_a0(c, P)
 
@@ -649,7 +679,7 @@ def ref_point_decompress(curve: str, enc: bytes, check_subgroup: bool = False) -
             return None, CODEC_INVALID
         if _bls_is_largest(c, P[1]) != bool(fl & 0x20):
             P = (P[0], (-P[1]) % c.p)
-        if check_subgroup and affine_mul(c, c.n, P) is not None:  # from_compressed, :299-313
+        if check_subgroup and not ref_g1_is_in_subgroup(P):  # from_compressed, :299-313 -> g1.rs:105-109
             return None, CODEC_INVALID
         return P, CODEC_OK
     x = int.from_bytes(enc[1:], "big")
@@ -707,6 +737,6 @@ def ref_g1_from_uncompressed(enc: bytes, check_subgroup: bool = False) -> Tuple[
         return None, (CODEC_INFINITY if x == 0 and y == 0 else CODEC_INVALID)
     if x >= c.p or y >= c.p or not on_curve(c, (x, y)):
         return None, CODEC_INVALID
-    if check_subgroup and affine_mul(c, c.n, (x, y)) is not None:
+    if check_subgroup and not ref_g1_is_in_subgroup((x, y)):
         return None, CODEC_INVALID
     return (x, y), CODEC_OK

@@ -288,3 +288,105 @@ def test_full_size_ed25519_mul_base_table_in_lds(engine, oracle):
     want_out, want_inf, _ = oracle.base("ed25519", ks[sample].tobytes(), threads=16)
     t = torch.from_numpy(sample).cuda()
     assert out_l[t].cpu().numpy().tobytes() == want_out and flags_l[t].cpu().numpy().tobytes() == want_inf
+
+
+# ---- BLS12-381 G1 through the endomorphism --------------------------------------------------------
+def test_bls_assume_subgroup_ladder_matches_oracle(engine, oracle):
+    """ECCX_ASSUME_SUBGROUP: k = k1 + k2 x^2, k P = k1 P + k2 (beta X, -Y) for P in G1 -- same bytes as
+    the reference algorithm for random scalars and for the scalars that stress the split: 0, 1,
+    x^2 - 1, x^2, x^2 + 1 (k1 = 0 / k2 = 1 boundaries), r - 1, r, r + 1, 2^255, 2^256 - 1 (largest
+    k2), and multiples of x^2 whose digits make the two halves meet (k1 P = +-k2 sigma'(P) cases come
+    from k = j (x^2 + 1): k1 = k2 = j)."""
+    from oracle import ecc_ref as R
+
+    curve = "bls12_381_g1"
+    x2 = R.BLS_X_ABS ** 2
+    r = W.order(curve)
+    special = [0, 1, 2, x2 - 1, x2, x2 + 1, 2 * x2, r - 1, r, r + 1, 1 << 255, (1 << 256) - 1,
+               ((1 << 256) - 1) // x2 * x2, 5 * (x2 + 1), 16 * (x2 + 1), 17 * (x2 + 1), 31 * x2 + 31,
+               (1 << 128) - 1, 1 << 127, (1 << 129) * x2 % (1 << 256)]
+    n = 1500
+    ks = bytearray(W.random_scalars(curve, n, seed=951).tobytes())
+    for i, v in enumerate(special):
+        ks[i * 32:(i + 1) * 32] = (v % (1 << 256)).to_bytes(32, "big")
+    # some full-range scalars (above r, any 256-bit string is accepted)
+    rng = np.random.Generator(np.random.PCG64(952))
+    for i in range(len(special), len(special) + 200):
+        ks[i * 32:(i + 1) * 32] = rng.integers(0, 256, size=32, dtype=np.uint8).tobytes()
+    ks = bytes(ks)
+    pts = _bases(oracle, curve, n, seed=953)
+    want = oracle.var(curve, ks, pts, threads=16)
+    got = engine.scalarmul_var(curve, ks, pts, assume_subgroup=True)
+    assert got[1] == want[1]
+    assert got[0] == want[0]
+    assert engine.scalarmul_var(curve, ks, pts) == got           # and the default ladder
+    # the flag is accepted and ignored on curves without the endomorphism path
+    k256 = W.random_scalars("p256r1", 64, seed=954).tobytes()
+    p256 = _bases(oracle, "p256r1", 64, seed=955)
+    assert engine.scalarmul_var("p256r1", k256, p256, assume_subgroup=True) == engine.scalarmul_var("p256r1", k256, p256)
+
+
+def test_bls_assume_subgroup_full_size(engine, oracle):
+    """BASELINE.json configs[4] at its single-GPU size through the endomorphism ladder: identical to
+    the default ladder on all 2^20 units (bases r_i G are in G1), sampled against the oracle."""
+    import torch
+
+    curve = "bls12_381_g1"
+    n = 1 << 20
+    ks = W.random_scalars(curve, n, seed=961)
+    d_k = torch.from_numpy(ks).cuda()
+    d_r = torch.from_numpy(W.random_scalars(curve, n, seed=962)).cuda()
+    pts, _ = engine.scalarmul_base_t(curve, d_r)
+    out, flags = engine.scalarmul_var_t(curve, d_k, pts)
+    out_g, flags_g = engine.scalarmul_var_t(curve, d_k, pts, assume_subgroup=True)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out_g) and torch.equal(flags, flags_g)
+    sample = np.random.Generator(np.random.PCG64(9)).choice(n, size=512, replace=False)
+    sample.sort()
+    t = torch.from_numpy(sample).cuda()
+    want = oracle.var(curve, ks[sample].tobytes(), pts[t].cpu().numpy().tobytes(), threads=16)
+    assert out_g[t].cpu().numpy().tobytes() == want[0] and flags_g[t].cpu().numpy().tobytes() == want[1]
+
+
+def test_bls_subgroup_test_on_cofactor_points(engine, oracle):
+    """The endomorphism test (g1.rs:90-109) on the points that make its ladders degenerate: points of
+    small order (3, 11, 33: multiples hit the point at infinity and P itself inside [|x|]P), points
+    of the full cofactor subgroup, G1 points, and sums of both -- against [r]P == infinity computed
+    with textbook affine arithmetic."""
+    from oracle import ecc_ref as R
+
+    c = R.BLS12_381_G1
+    x = -R.BLS_X_ABS
+    h = (x - 1) ** 2 // 3
+    assert (h * c.n - (c.p + 1 - (x + 1))) == 0      # #E(Fp) = p + 1 - t with t = x + 1
+    pts = []
+    xx = 1
+    raw = []
+    while len(raw) < 12:                             # arbitrary curve points (order h * r up to factors)
+        xx += 1
+        P = R.ref_w_decompress_xy(c, xx, bool(xx & 1))
+        if P is not None:
+            raw.append(P)
+    G = (c.gx, c.gy)
+    for P in raw:
+        T = R.affine_mul(c, c.n, P)                  # in the cofactor subgroup
+        pts.append(P)
+        if T is not None:
+            pts.append(T)
+            for f in (3, 11, 33):
+                S = R.affine_mul(c, h // f, T) if h % f == 0 else None
+                if S is not None:
+                    pts.append(S)                    # order divides f
+            pts.append(R.affine_add(c, T, R.affine_mul(c, 12345, G)))   # mixed: not in G1
+    pts += [R.affine_mul(c, k, G) for k in (1, 2, 3, c.n - 1, 0xDEADBEEF)]
+    small = [P for P in pts if R.affine_mul(c, 33, P) is None]
+    assert small, "no small-order point was generated"
+    enc = b"".join(R.ref_g1_to_uncompressed(P) for P in pts)
+    want_in = [R.affine_mul(c, c.n, P) is None for P in pts]
+    assert any(want_in) and not all(want_in)
+    assert want_in == [R.ref_g1_is_in_subgroup(P) for P in pts]
+    out, flags = engine.point_decompress("bls12_381_g1", enc, uncompressed=True, check_subgroup=True)
+    assert list(flags) == [0 if w else 2 for w in want_in]
+    for i, (P, w) in enumerate(zip(pts, want_in)):
+        rec = out[96 * i:96 * (i + 1)]
+        assert rec == (P[0].to_bytes(48, "big") + P[1].to_bytes(48, "big") if w else bytes(96))

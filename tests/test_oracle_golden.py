@@ -313,3 +313,28 @@ def test_completeness_properties(name):
     assert aff(lhs) == aff(R.ref_scalar_mul_fixed_window(c, G, be((a + b) % c.n, c.sb)))
     k = be(rng.randrange(1, c.n), c.sb)                                            # mul_base == generic
     assert aff(R.ref_mul_base_table(c, R.comb_table(name), k)) == aff(R.ref_scalar_mul_fixed_window(c, G, k))
+
+
+def test_g1_endomorphism_subgroup_test_agrees_with_the_definition():
+    """The oracle's restatement of PointAffine::is_in_subgroup (sigma(P) == [-x^2]P, g1.rs:90-109) with
+    the reference's beta (tests/golden/params.json, from src/params/bls12_381.rs:100) against the
+    definition [r]P == infinity, on G1 points, arbitrary curve points and cofactor-subgroup points."""
+    c = R.BLS12_381_G1
+    assert int(golden("params.json")["bls12_381_g1"]["beta"], 16) == R.BLS_BETA
+    assert pow(R.BLS_BETA, 3, c.p) == 1 and R.BLS_BETA != 1
+    G = (c.gx, c.gy)
+    pts = [R.affine_mul(c, k, G) for k in (1, 2, 7, c.n - 1, 0x1234567890ABCDEF)]
+    x = 1
+    while len(pts) < 15:
+        x += 1
+        P = R.ref_w_decompress_xy(c, x, bool(x & 1))
+        if P is not None:
+            pts.append(P)
+            pts.append(R.affine_mul(c, c.n, P))
+    for P in pts:
+        assert R.ref_g1_is_in_subgroup(P) == (R.affine_mul(c, c.n, P) is None)
+    assert R.ref_g1_is_in_subgroup(None)
+    # the G1 encodings the reference's tests hold decode under the check
+    for e in golden("bls_g1.json")["compressed"]:
+        P, st = R.ref_point_decompress("bls12_381_g1", bytes.fromhex(e["bytes"]), check_subgroup=True)
+        assert st == R.CODEC_OK and P is not None

@@ -40,6 +40,42 @@ def limbs(x, n):
     return [(x >> (32 * i)) & 0xFFFFFFFF for i in range(n)]
 
 
+# ---- BLS12-381 G1 endomorphism (subgroup test, GLV split) ------------------------------------
+# seed x = -0xd201000000010000; group order r = x^4 - x^2 + 1, so lambda = -x^2 satisfies
+# lambda^2 + lambda + 1 = 0 mod r and sigma(X, Y) = (beta X, Y) acts on G1 as [lambda] for one of
+# the two primitive cube roots of unity beta in Fp.  Which one is settled by computing [x^2]G with
+# textbook affine arithmetic: [x^2]G = -sigma(G) = (beta Gx, -Gy).
+BLS_X_ABS = 0xD201000000010000
+
+
+def _bls_beta():
+    _, p, _, gx, gy, _, _, _ = CURVES[3]
+
+    def add(P, Q):
+        if P is None:
+            return Q
+        if Q is None:
+            return P
+        (x1, y1), (x2, y2) = P, Q
+        if x1 == x2:
+            if (y1 + y2) % p == 0:
+                return None
+            lam = 3 * x1 * x1 * pow(2 * y1, -1, p) % p
+        else:
+            lam = (y2 - y1) * pow(x2 - x1, -1, p) % p
+        x3 = (lam * lam - x1 - x2) % p
+        return x3, (lam * (x1 - x3) - y1) % p
+
+    acc = None
+    for bit in bin(BLS_X_ABS * BLS_X_ABS)[2:]:
+        acc = add(acc, acc)
+        if bit == "1":
+            acc = add(acc, (gx, gy))
+    beta = acc[0] * pow(gx, -1, p) % p
+    assert pow(beta, 3, p) == 1 and beta != 1 and (p - acc[1]) % p == gy
+    return beta
+
+
 def arr(name, vals):
     body = ", ".join("0x%08xu" % v for v in vals)
     return "  static constexpr uint32_t %s[%d] = {%s};" % (name, len(vals), body)
@@ -216,7 +252,17 @@ def main():
     emit_unsat(out, "P384U", "P384", CURVES[1][1], CURVES[1][3], CURVES[1][4], 28, 14, 0,
                solinas=((128, -1), (96, -1), (32, 1)), sparse=True, extra=bb(1), root_exp=(CURVES[1][1] + 1) // 4)
     emit_unsat(out, "P521U", "P521", CURVES[2][1], CURVES[2][3], CURVES[2][4], 29, 18, 2, extra=bb(2), root_exp=(CURVES[2][1] + 1) // 4)
-    emit_unsat(out, "BLS12_381U", "BLS12_381", CURVES[3][1], CURVES[3][3], CURVES[3][4], 28, 14, 1, extra=bb(3), root_exp=(CURVES[3][1] + 1) // 4)
+    emit_unsat(out, "BLS12_381U", "BLS12_381", CURVES[3][1], CURVES[3][3], CURVES[3][4], 28, 14, 1,
+               extra=bb(3) + (("BETA", _bls_beta()),), root_exp=(CURVES[3][1] + 1) // 4)
+    # scalar split k = k1 + k2 * x^2 (ECCX_ASSUME_SUBGROUP): x^2 and floor(2^256 / x^2) in 32-bit limbs
+    x2 = BLS_X_ABS * BLS_X_ABS
+    out.append("struct BLS12_381_GLV {")
+    out.append("  static constexpr uint64_t SEED_ABS = 0x%016xull;  // |x|, x the curve's seed (negative)" % BLS_X_ABS)
+    out.append(arr("X2", limbs(x2, 4)))
+    out.append(arr("MU", limbs((1 << 256) // x2, 5)))
+    out.append("  static constexpr int K_BITS = %d;  // bits of the halves: k1 < x^2, k2 <= (2^256 - 1) / x^2" % max(x2.bit_length(), (((1 << 256) - 1) // x2).bit_length()))
+    out.append("};")
+    out.append("")
     L = 8
     out.append("struct ED25519;")
     emit_unsat(out, "ED25519U", "ED25519", P25519, ED_GX, ED_GY, 29, 9, 3, extra=(("D2", 2 * ED_D % P25519), ("D", ED_D), ("SQRT_M1", pow(2, (P25519 - 1) // 4, P25519))),
