@@ -193,6 +193,7 @@ ECCX_DEV void glv_split(uint32_t (&k1)[5], uint32_t (&k2)[5], const uint8_t* __r
         carry = t >> 32;
       }
     }
+    if (i + 4 < 5) qx[i + 4] = (uint32_t)carry;  // the row's last carry (only row 0 still lands below 2^160)
   }
   uint32_t r[5];
   {
