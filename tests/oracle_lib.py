@@ -88,8 +88,10 @@ _cached = None
 def load() -> Oracle:
     global _cached
     if _cached is None:
-        so = os.path.join(ORACLE_DIR, "liboracle.so")
+        # ECCX_ORACLE_SAN=1: the AddressSanitizer + UBSan build (tools/run_sanitizers.sh preloads the runtimes)
+        san = os.environ.get("ECCX_ORACLE_SAN", "0") == "1"
+        so = os.path.join(ORACLE_DIR, "liboracle_san.so" if san else "liboracle.so")
         if not os.path.exists(so):
-            subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"] + (["SAN=1"] if san else []))
         _cached = Oracle(ctypes.CDLL(so))
     return _cached
