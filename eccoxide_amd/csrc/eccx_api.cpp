@@ -29,6 +29,7 @@ constexpr uint32_t K_VALIDATE = 1u << 2;
 constexpr uint32_t K_OUT_ROWS = 1u << 3;
 constexpr uint32_t K_NEGATE_B = 1u << 5;  // second operand negated: a - b, u1*G - u2*Q
 constexpr uint32_t K_CT_SCAN = 1u << 6;   // table lookups scan every entry (ECCX_CT_SCAN)
+constexpr uint32_t K_ONLY_MARKED = 1u << 7;  // variable base: redo only the units marked 0xFE
 
 const CurveOps* ops_of(int curve) {
   switch (curve) {
@@ -132,14 +133,21 @@ int launch_var(eccx_ctx* ctx, const CurveOps* ops, size_t n, const uint8_t* d_sc
                bool glv = false) {
   if (n == 0) return ECCX_OK;
   const bool fast = !mirror && ops->var_fast && !d_proj && !(kopts & K_OUT_TABLE);
-  if (fast && glv && ops->var_glv && d_points) {
-    // bases known to be in the prime-order subgroup: the endomorphism ladder (kernels_bls.hpp)
-    const int grid = ops->var_glv_grid(ctx->cus, n);
-    int rc = ensure_scratch(ctx, ops->glv_row_words, grid);
+  if (fast && ops->var_coz && d_points && !(kopts & K_BASE_IS_GENERATOR)) {
+    // a = 0 curves: the ladder over a co-Z table (kernels_bls.hpp); glv: bases known to be in the
+    // prime-order subgroup.  Units with a base point of order <= 16 come back marked and are redone
+    // by the generic ladder, which otherwise only reads the flags.
+    const int g = glv ? 1 : 0;
+    const int grid = ops->var_coz_grid(ctx->cus, n, g);
+    const int grid2 = ops->var_fast_grid ? ops->var_fast_grid(ctx->cus, n) : grid_for(ctx, n);
+    int rc = ensure_scratch(ctx, ops->coz_row_words, grid);
+    if (rc) return rc;
+    rc = ensure_scratch(ctx, ops->info.row5_words, grid2);
     if (rc) return rc;
     rc = ensure_rows(ctx, ops, n);
     if (rc) return rc;
-    HIP_TRY(ctx, ops->var_glv(grid, s, n, d_scalars, d_points, ctx->jac, d_flags, ctx->scratch, kopts));
+    HIP_TRY(ctx, ops->var_coz(grid, s, n, d_scalars, d_points, ctx->jac, d_flags, ctx->scratch, kopts, g));
+    HIP_TRY(ctx, ops->var_fast(grid2, s, n, d_scalars, d_points, ctx->jac, d_flags, ctx->scratch, kopts | K_ONLY_MARKED));
     HIP_TRY(ctx, ops->to_affine_var(norm_grid(ctx, n), s, n, ctx->jac, d_out, d_flags));
     return ECCX_OK;
   }
@@ -547,8 +555,8 @@ int eccx_reserve(eccx_ctx* ctx, int curve, size_t max_n, uint32_t what) {
     const int grid = ops->var_fast_grid ? ops->var_fast_grid(ctx->cus, max_n) : grid_for(ctx, max_n);
     rc = ensure_scratch(ctx, ops->info.row5_words, grid);
     if (rc) return rc;
-    if (ops->var_glv) {  // ECCX_ASSUME_SUBGROUP: wider rows
-      rc = ensure_scratch(ctx, ops->glv_row_words, ops->var_glv_grid(ctx->cus, max_n));
+    if (ops->var_coz) {  // a = 0 curves: the co-Z ladder's slab (both forms)
+      rc = ensure_scratch(ctx, ops->coz_row_words, std::max(ops->var_coz_grid(ctx->cus, max_n, 0), ops->var_coz_grid(ctx->cus, max_n, 1)));
       if (rc) return rc;
     }
   }

@@ -23,6 +23,7 @@ enum : uint32_t {
   OPT_VALIDATE = 1u << 2,           // reject non-canonical / off-curve input points (flag 2)
   OPT_OUT_ROWS = 1u << 3,           // write the un-normalised result as a row of Montgomery limbs
                                     // (X, Y, Z) for k_batch_to_affine instead of normalising here
+  OPT_ONLY_MARKED = 1u << 7,        // variable base: process only the units whose flag is 0xFE (redo marker)
   OPT_CT_SCAN = 1u << 6,            // table lookups read EVERY entry and keep the wanted one with selects
                                     // (select_from_table, projective.rs:427-434 / curve25519.rs:862-869):
                                     // no memory address and no branch depends on a scalar digit

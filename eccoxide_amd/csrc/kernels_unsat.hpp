@@ -163,11 +163,17 @@ ECCX_DEV void ujac_add_raw(UJac<CU>& r, bool& h_zero, bool& r_zero, U<CU, 1, 3>&
   auto r2 = u_sqr(rr);
   auto x3 = u_reduce(u_sub(u_sub(u_sub(r2, hhh), v), v));
   auto tt = u_sub(v, x3);
-  auto y3a = u_mul(rr, tt);
-  auto s1h = u_mul(s1, hhh);
   auto z3a = u_mul(p.z, e.z);
   r.x = x3;
-  r.y = u_reduce(u_sub(y3a, s1h));
+  if constexpr (CU::KIND == UK_MONT) {
+    // Y3 = r*(v - x3) + (4p - s1)*h^3: two products, one reduction (the general Montgomery
+    // reduction is half of every product there)
+    r.y = u_fit<1, 3>(u_mul_add(rr, tt, u_neg(s1), hhh));
+  } else {
+    auto y3a = u_mul(rr, tt);
+    auto s1h = u_mul(s1, hhh);
+    r.y = u_reduce(u_sub(y3a, s1h));
+  }
   r.z = u_fit<UJac<CU>::ZK, UJac<CU>::ZV>(u_mul(z3a, h));
 }
 
@@ -267,8 +273,13 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_var_uns
   auto row = [&](uint32_t e) { return slab + (size_t)e * WG * W5; };
   for (size_t base = (size_t)blockIdx.x * WG; base < n; base += (size_t)gridDim.x * WG) {
     const size_t gid = base + threadIdx.x;
-    const bool active = gid < n;
+    bool active = gid < n;
     const size_t idx = active ? gid : n - 1;
+    if (opts & OPT_ONLY_MARKED) {
+      // fix-up pass behind the co-Z ladder (kernels_bls.hpp): only the units it marked are redone
+      active = active && flags[idx] == 0xFE;
+      if (__builtin_amdgcn_ballot_w64(active) == 0) continue;
+    }
 
     UJac<CU> q;
     bool rejected = false;
@@ -418,10 +429,14 @@ ECCX_DEV void ujac_madd_raw(UJac<CU>& r, bool& h_zero, bool& r_zero, const UJac<
   auto v = u_mul(p.x, hh);
   auto r2 = u_sqr(rr);
   auto x3 = u_reduce(u_sub(u_sub(u_sub(r2, hhh), v), v));
-  auto y3a = u_mul(rr, u_sub(v, x3));
-  auto y1h = u_mul(p.y, hhh);
   r.x = x3;
-  r.y = u_reduce(u_sub(y3a, y1h));
+  if constexpr (CU::KIND == UK_MONT) {
+    r.y = u_fit<1, 3>(u_mul_add(rr, u_sub(v, x3), u_neg(p.y), hhh));  // one reduction for both products
+  } else {
+    auto y3a = u_mul(rr, u_sub(v, x3));
+    auto y1h = u_mul(p.y, hhh);
+    r.y = u_reduce(u_sub(y3a, y1h));
+  }
   r.z = u_fit<UJac<CU>::ZK, UJac<CU>::ZV>(u_mul(p.z, h));
 }
 

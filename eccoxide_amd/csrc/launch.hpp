@@ -80,14 +80,16 @@ struct CurveOps {
   hipError_t (*point_add_u)(int grid, hipStream_t s, size_t n, const uint8_t* a, const uint8_t* a_inf, const uint8_t* b,
                             const uint8_t* b_inf, uint32_t* rows, uint8_t* flags, uint32_t opts);
   hipError_t (*to_affine_add_u)(int grid, hipStream_t s, size_t n, const uint32_t* rows, uint8_t* out, uint8_t* flags);
-  // curves with an efficient endomorphism (bls12_381_g1; null / 0 elsewhere), kernels_bls.hpp:
-  // the variable-base ladder for bases known to be in the prime-order subgroup (rows for
-  // to_affine_var; scratch rows of glv_row_words), and the subgroup membership test applied in
-  // place to decompressed points (flags 0 -> 2 and zero bytes for points outside the subgroup)
-  hipError_t (*var_glv)(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint8_t* points, uint32_t* rows,
-                        uint8_t* flags, uint32_t* scratch, uint32_t opts);
-  int (*var_glv_grid)(int cus, size_t n);
-  int glv_row_words;
+  // a = 0 curves (bls12_381_g1; null / 0 elsewhere), kernels_bls.hpp: the variable-base ladder over a
+  // co-Z window table (mixed additions); glv != 0 selects the endomorphism form for bases known to be
+  // in the prime-order subgroup.  Rows for to_affine_var; scratch rows of coz_row_words.  Units whose
+  // base point has order <= 16 come back marked (flag 0xFE) and are redone by var_fast launched with
+  // the only-marked option.  subgroup_check: the membership test applied in place to decompressed
+  // points (flags 0 -> 2 and zero bytes for points outside the subgroup)
+  hipError_t (*var_coz)(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint8_t* points, uint32_t* rows,
+                        uint8_t* flags, uint32_t* scratch, uint32_t opts, int glv);
+  int (*var_coz_grid)(int cus, size_t n, int glv);
+  int coz_row_words;
   hipError_t (*subgroup_check)(int grid, hipStream_t s, size_t n, uint8_t* xy, uint8_t* flags);
 };
 // units normalised per lane with one inversion: 16 where the prefix products fit the register

@@ -207,6 +207,45 @@ ECCX_DEV void u_mul_core_mont(uint32_t (&r)[C::N], const uint32_t (&a)[C::N], co
   for (int i = 0; i < N; ++i) r[i] = t[i];
 }
 
+// (a*b + c*d) / R with ONE reduction (general Montgomery, kind 1): both products are accumulated
+// into the same columns before the Montgomery factor of a column is taken.  Where a formula adds
+// two products -- Y3 = r*(v - x3) - s1*h^3 -- this saves the N*N reduction products and N column
+// extractions of the second one; a subtraction is written as (4p - c)*d (u_neg).
+template <class C>
+ECCX_DEV void u_mul2_core_mont(uint32_t (&r)[C::N], const uint32_t (&a)[C::N], const uint32_t (&b)[C::N],
+                               const uint32_t (&c)[C::N], const uint32_t (&d)[C::N]) {
+  constexpr int N = C::N;
+  static_assert(C::KIND == UK_MONT, "written for the general Montgomery fields");
+  uint32_t m[N], t[N];
+  uint64_t acc = 0;
+  UMacQ<false> qa;
+  UMacQ<true> qm;
+#pragma unroll
+  for (int k = 0; k < 2 * N - 1; ++k) {
+    const int lo = k < N ? 0 : k - N + 1, hi = k < N ? k : N - 1;
+#pragma unroll
+    for (int i = lo; i <= hi; ++i) qa.push(acc, a[i], b[k - i]);
+#pragma unroll
+    for (int i = lo; i <= hi; ++i) qa.push(acc, c[i], d[k - i]);
+    qa.flush(acc);
+#pragma unroll
+    for (int i = lo; i <= (k < N ? k - 1 : N - 1); ++i) {
+      if (C::P[k - i] != 0) qm.push(acc, m[i], C::P[k - i]);
+    }
+    qm.flush(acc);
+    if (k < N) {
+      m[k] = ((uint32_t)acc * C::N0B) & C::MASK;
+      umad1_k(acc, m[k], C::P[0]);
+    } else {
+      t[k - N] = (uint32_t)acc & C::MASK;
+    }
+    acc >>= C::B;
+  }
+  t[N - 1] = (uint32_t)acc;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r[i] = t[i];
+}
+
 // Mersenne product / square (kind 2), p = 2^k - 1 with B*N - k = S: the product's upper half
 // has weight 2^(B*N) = 2^S (mod p), so a_i * b_j with i + j >= N is accumulated into column
 // i + j - N times 2^S.  Inputs tight; output tight (digit 1 may exceed 2^B by the last carry).
@@ -430,6 +469,19 @@ ECCX_DEV auto u_mul(const U<C, K1, V1>& a, const U<C, K2, V2>& b) {
     u_mul_core<C, false, false>(r.v, a.v, b.v);
     return r;
   }
+}
+
+// a*b + c*d with one reduction (general Montgomery fields only).  The caller brings operands within
+// the column budget: N*(K1*K2 + K3*K4)*2^(2B) + the reduction's N*2^(2B) must fit 64 bits.
+template <class C, int K1, int V1, int K2, int V2, int K3, int V3, int K4, int V4>
+ECCX_DEV auto u_mul_add(const U<C, K1, V1>& a, const U<C, K2, V2>& b, const U<C, K3, V3>& c, const U<C, K4, V4>& d) {
+  static_assert(C::KIND == UK_MONT, "merged products are implemented for the general Montgomery fields");
+  static_assert(K1 * K2 + K3 * K4 <= UB<C>::KKMAX, "two products overflow the columns: reduce an operand first");
+  constexpr int VO = (int)(((uint32_t)(V1 * V2 + V3 * V4) + C::RP - 1) / C::RP) + 1;
+  static_assert(VO <= 3, "result too large: reduce an operand first");
+  U<C, 1, VO> r;
+  u_mul2_core_mont<C>(r.v, a.v, b.v, c.v, d.v);
+  return r;
 }
 
 template <class C, int K1, int V1>

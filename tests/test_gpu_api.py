@@ -390,3 +390,51 @@ def test_bls_subgroup_test_on_cofactor_points(engine, oracle):
     for i, (P, w) in enumerate(zip(pts, want_in)):
         rec = out[96 * i:96 * (i + 1)]
         assert rec == (P[0].to_bytes(48, "big") + P[1].to_bytes(48, "big") if w else bytes(96))
+
+
+def test_bls_low_order_bases_among_ordinary_ones(engine, oracle):
+    """The co-Z ladder marks units whose base point has order <= 16 (its table build degenerates) and
+    the generic ladder redoes exactly those: points of order 3, 11, 33 and other cofactor-subgroup
+    points interleaved with G1 points inside the same wavefronts -- every unit against the oracle."""
+    from oracle import ecc_ref as R
+
+    c = R.BLS12_381_G1
+    x = -R.BLS_X_ABS
+    h = (x - 1) ** 2 // 3
+    odd = []
+    xx = 1
+    while len(odd) < 6:
+        xx += 1
+        P = R.ref_w_decompress_xy(c, xx, bool(xx & 1))
+        if P is None:
+            continue
+        T = R.affine_mul(c, c.n, P)
+        if T is None:
+            continue
+        odd.append(T)                                   # full cofactor order
+        for f in (3, 11, 33):
+            if h % f == 0:
+                S = R.affine_mul(c, h // f, T)
+                if S is not None:
+                    odd.append(S)
+    assert any(R.affine_mul(c, 3, P) is None for P in odd), "no point of order 3 among the test points"
+    n = 640
+    pts = bytearray(_bases(oracle, "bls12_381_g1", n, seed=971))
+    where = list(range(5, n, 37))[: len(odd)]
+    for i, P in zip(where, odd):
+        pts[i * 96:(i + 1) * 96] = P[0].to_bytes(48, "big") + P[1].to_bytes(48, "big")
+    pts = bytes(pts)
+    ks = bytearray(W.random_scalars("bls12_381_g1", n, seed=972).tobytes())
+    for j, i in enumerate(where):                        # small and structured scalars on the odd points too
+        if j % 3 == 0:
+            ks[i * 32:(i + 1) * 32] = (3 * 11 * (j + 1)).to_bytes(32, "big")
+    ks = bytes(ks)
+    want = oracle.var("bls12_381_g1", ks, pts, threads=16)
+    got = engine.scalarmul_var("bls12_381_g1", ks, pts)
+    assert got[1] == want[1] and got[0] == want[0]
+    assert 1 in want[1]                                  # some multiples really are the point at infinity
+    # under ECCX_ASSUME_SUBGROUP the G1 units are still right (the others are the caller's problem)
+    got_g = engine.scalarmul_var("bls12_381_g1", ks, pts, assume_subgroup=True)
+    for i in range(n):
+        if i not in where:
+            assert got_g[0][i * 96:(i + 1) * 96] == want[0][i * 96:(i + 1) * 96] and got_g[1][i] == want[1][i]
