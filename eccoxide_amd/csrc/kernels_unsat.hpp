@@ -325,15 +325,23 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_var_uns
       d = (m >> 1) + (m & 1u);
       neg = (s & 1u) != 0;
     };
-    int b = 0;                    // table-build step: 0 -> T[2] = 2P, 1..14 -> T[b+2] = T[b+1] + P
+    // table-build step b makes T[b+2]: an even entry by DOUBLING T[(b+2)/2] (a doubling costs half an
+    // addition), an odd one as T[b+1] + P with T[b+1] still in q from the step before
+    int b = 0;
     int win = NWIN - 1, sub = 5;  // the top window needs no doublings
     bool fix_pending = false, fix_lane = false;
     for (;;) {
       const bool building = b < 15;
       if (!building && win < 0) break;
-      const bool do_dbl = fix_pending || (building ? (b == 0) : (sub < 5));
+      const bool do_dbl = fix_pending || (building ? ((b & 1) == 0) : (sub < 5));
       bool step_done;
       if (do_dbl) {
+        if (building && !fix_pending && b > 0) {
+          UEntry<CU> half;
+          uentry_load<CU>(half, row((b + 2) >> 1));
+          q.x = half.x; q.y = half.y;
+          q.z = u_as<UJac<CU>::ZK, UJac<CU>::ZV>(half.z);
+        }
         UJac<CU> t;
         ujac_dbl<CU>(t, q);
         if (fix_pending) {

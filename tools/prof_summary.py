@@ -47,15 +47,30 @@ def trace(db_path):
 def pmc(db_path):
     db = sqlite3.connect(db_path)
     rows = db.execute("select kernel_name, grid_size, counter_name, value from counters_collection").fetchall()
-    agg = {}
-    for name, grid, counter, value in rows:
-        k = (short(name), grid, counter)
-        a = agg.setdefault(k, [0, 0.0])
-        a[0] += 1
-        a[1] += value
+    # one row per (dispatch, counter instance): sum the instances of a dispatch first, then take the
+    # MEDIAN over the dispatches of a (kernel, grid) -- the timed launches of a bench run are identical,
+    # while a one-off launch of the same kernel with another batch (the comb-table build runs the
+    # variable-base kernel over windows x 65536 units) would skew an average
+    return _pmc_median(db)
+
+
+def _pmc_median(db):
+    cols = [r[1] for r in db.execute("pragma table_info(counters_collection)").fetchall()]
+    key = "dispatch_id" if "dispatch_id" in cols else ("id" if "id" in cols else None)
+    if key is None:
+        rows = db.execute("select kernel_name, grid_size, counter_name, value, rowid from counters_collection").fetchall()
+    else:
+        rows = db.execute(f"select kernel_name, grid_size, counter_name, value, {key} from counters_collection").fetchall()
+    per = {}
+    for name, grid, counter, value, disp in rows:
+        per.setdefault((short(name), grid, counter), {}).setdefault(disp, 0.0)
+        per[(short(name), grid, counter)][disp] += value
     out = {}
-    for (name, grid, counter), (cnt, total) in agg.items():
-        out.setdefault(f"{name} grid={grid}", {})[counter] = {"dispatches": cnt, "avg_per_dispatch": total / cnt}
+    for (name, grid, counter), by_disp in per.items():
+        vals = sorted(by_disp.values())
+        out.setdefault(f"{name} grid={grid}", {})[counter] = {
+            "dispatches": len(vals), "avg_per_dispatch": vals[len(vals) // 2], "mean_per_dispatch": sum(vals) / len(vals),
+            "min_per_dispatch": vals[0], "max_per_dispatch": vals[-1], "statistic": "median over dispatches"}
     return out
 
 
