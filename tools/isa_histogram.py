@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Per-body instruction histograms of a kernel, from the gfx950 assembly hipcc emits.
+
+    python tools/isa_histogram.py k_p256.hip 'k_scalarmul_var_unsat<eccx::P256U, false>' > profiles/r02_isa_p256r1_var.txt
+
+Compiles eccoxide_amd/csrc/<unit> with the library's flags (device code only, -S), cuts the named
+kernel into basic blocks and prints, for every block with at least --min-mads multiplies, the
+instruction mix and its weight at the issue costs measured on MI355X
+(profiles/r01_valu_rates.jsonl: v_mad_u64_u32 5.03 cycles, three-operand / 64-bit VALU 4.2, two-operand
+VALU 2.5 per wave instruction per SIMD).  The big blocks of the ladders are the doubling body, the
+addition body (often split in two by a branch) and the table-entry body.
+"""
+import argparse
+import collections
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "eccoxide_amd", "csrc")
+COST = {"v_mad_u64_u32": 5.03, "v_mad_i64_i32": 5.1, "v_lshrrev_b64": 4.2, "v_ashrrev_i64": 4.2, "v_lshlrev_b64": 4.2,
+        "v_lshl_add_u64": 4.5, "v_add3_u32": 4.2, "v_alignbit_b32": 4.2, "v_lshl_add_u32": 4.2, "v_or3_b32": 4.2,
+        "v_bitop3_b32": 4.2, "v_xad_u32": 4.2, "v_mul_lo_u32": 4.35, "v_mul_hi_u32": 4.2, "v_cndmask_b32_e64": 4.2}
+DEFAULT_COST = 2.5
+
+
+def demangle(names):
+    out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout
+    return dict(zip(names, out.strip().split("\n")))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("unit")
+    ap.add_argument("kernel", help="substring of the demangled kernel name")
+    ap.add_argument("--min-mads", type=int, default=150)
+    ap.add_argument("--asm", help="reuse an assembly file instead of compiling")
+    args = ap.parse_args()
+    asm = args.asm
+    if not asm:
+        asm = os.path.join(tempfile.mkdtemp(), "unit.s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-mllvm",
+                               "-pragma-unroll-threshold=1000000", "-S", "--cuda-device-only", os.path.join(CSRC, args.unit),
+                               "-o", asm], stderr=subprocess.DEVNULL)
+    txt = open(asm).read()
+    labels = re.findall(r"^(_Z\w+):", txt, flags=re.M)
+    names = demangle(labels)
+    want = [m for m in labels if args.kernel in names[m] and "k_" in names[m]]
+    if not want:
+        sys.exit("kernel not found; kernels: " + ", ".join(sorted(set(v.split("(")[0] for v in names.values() if "k_" in v))))
+    mangled = want[0]
+    start = txt.index(mangled + ":")
+    end = txt.index(".Lfunc_end", start)
+    body = txt[start:end].split("\n")
+    meta = {}
+    mm = re.search(r"\.name:\s+%s.*?(?=\n  - |\Z)" % re.escape(mangled), txt, flags=re.S)
+    if mm:
+        for key in ("vgpr_count", "agpr_count", "sgpr_count", "private_segment_fixed_size", "group_segment_fixed_size"):
+            m2 = re.search(r"\.%s:\s+(\d+)" % key, mm.group(0))
+            if m2:
+                meta[key] = int(m2.group(1))
+    blocks, cur = [], ["<entry>", collections.Counter()]
+    for line in body:
+        m = re.match(r"^(\.LBB\w+):", line)
+        if m:
+            blocks.append(cur)
+            cur = [m.group(1), collections.Counter()]
+            continue
+        m = re.match(r"^\s+([a-z][a-z_0-9]*)", line)
+        if m:
+            cur[1][m.group(1)] += 1
+    blocks.append(cur)
+    print(f"# {names[mangled].split('(')[0]}")
+    print(f"# unit {args.unit}; resources: {meta}")
+    print("# block: instructions / VALU / multiplies; share of the block's issue cycles spent on multiplies")
+    for name, c in blocks:
+        mads = c["v_mad_u64_u32"] + c["v_mad_i64_i32"]
+        if mads < args.min_mads:
+            continue
+        valu = {k: v for k, v in c.items() if k.startswith("v_")}
+        cyc = sum(v * COST.get(k.replace("_e32", ""), COST.get(k, DEFAULT_COST)) for k, v in valu.items())
+        mad_cyc = c["v_mad_u64_u32"] * COST["v_mad_u64_u32"] + c["v_mad_i64_i32"] * COST["v_mad_i64_i32"]
+        tot = sum(c.values())
+        print(f"\n{name}: {tot} instructions, {sum(valu.values())} VALU, {mads} multiplies "
+              f"({100.0 * mads / max(1, sum(valu.values())):.1f} % of VALU instructions, {100.0 * mad_cyc / cyc:.1f} % of VALU issue cycles)")
+        for k, v in c.most_common():
+            print(f"    {v:6d}  {k}")
+
+
+if __name__ == "__main__":
+    main()
