@@ -71,11 +71,11 @@ def _var_unsat(n, nz, sb, a0, inv, sat_pairs, mont=True, norm_u=8, glv_bits=0):
         dbl, madd = cost(2, 5), cost(8, 3, 10)
         per_entry = cost(4, 1) + (cost(1, 0) if glv_bits else 0)
         total = dbl + 14 * madd + 15 * per_entry + (cost(1, 0) if glv_bits else 0)   # (+ beta x of entry 16)
-        total += (nwin - 1) * 5 * dbl + nwin * madd * (2 if glv_bits else 1) + cost(1, 0)
+        total += (nwin - 1) * 5 * dbl + (nwin * (2 if glv_bits else 1) - 1) * madd + cost(1, 0)   # the top window's first entry is loaded, not added
         return {"mad": total + conv + norm, "pair": 0}
     nwin = (8 * sb + 1 + 4) // 5
     dbl, add = cost(4, 4), cost(11, 3)
-    total = 8 * dbl + 7 * add + 15 * cost(1, 1) + (nwin - 1) * 5 * dbl + nwin * add
+    total = 8 * dbl + 7 * add + 15 * cost(1, 1) + (nwin - 1) * 5 * dbl + (nwin - 1) * add   # the top window's entry is loaded, not added
     return {"mad": total + conv + norm, "pair": 0}
 
 
@@ -133,6 +133,14 @@ ED_STEP_KERNELS = {
     ("base", "default"): ["k_ed_scalarmul_base_unsat<eccx::ED25519U>", "k_batch_to_affine_unsat<eccx::ED25519U, 2,"],
     ("base", "lds"): ["k_ed_scalarmul_base_lds6<eccx::ED25519U>", "k_batch_to_affine_unsat<eccx::ED25519U, 2,"],
 }
+# bls12_381_g1 variable base: the co-Z ladder, the generic ladder as its fix-up pass (reads the flags,
+# redoes marked units: none in this workload), the normalisation
+BLS_STEP_KERNELS = {
+    ("var", "default"): ["k_scalarmul_coz_unsat<eccx::BLS12_381U, eccx::BLS12_381_GLV, false>",
+                         "k_scalarmul_var_unsat<eccx::BLS12_381U, false>", "k_batch_to_affine_unsat<eccx::BLS12_381U, 1,"],
+    ("var", "glv"): ["k_scalarmul_coz_unsat<eccx::BLS12_381U, eccx::BLS12_381_GLV, true>",
+                     "k_scalarmul_var_unsat<eccx::BLS12_381U, false>", "k_batch_to_affine_unsat<eccx::BLS12_381U, 1,"],
+}
 CURVE_STRUCTS = {"p256r1": ("P256", "P256U"), "p384r1": ("P384", "P384U"), "p521r1": ("P521", "P521U"),
                  "bls12_381_g1": ("BLS12_381", "BLS12_381U"), "ed25519": ("ED25519", "ED25519U")}
 
@@ -152,6 +160,8 @@ def measured_traffic(workload, curve, op, variant):
     path = os.path.join(ROOT, rel)
     table = ED_STEP_KERNELS if curve == "ed25519" and op != "x25519" else STEP_KERNELS
     pats = table.get((op, variant))
+    if curve == "bls12_381_g1" and (op, variant) in BLS_STEP_KERNELS:
+        pats = BLS_STEP_KERNELS[(op, variant)]
     if not os.path.exists(path) or not pats:
         return None
     with open(path) as f:

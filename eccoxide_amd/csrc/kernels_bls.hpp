@@ -451,7 +451,26 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_coz_uns
               if constexpr (GLV) u3_store<CU>(row(d), xs, ys, u_fit<1, 3>(u_mul_k<CU>(xs, CU::BETA)));
               else u3_store<CU>(row(d), xs, ys, one);
             }
-            u_set_zero(q.z);  // the accumulator starts at infinity
+            // the top window's (first) addition has nothing to add to: the accumulator starts as that
+            // signed entry -- affine on E', so Z = 1 -- or at infinity for digit 0
+            uint32_t d;
+            bool neg;
+            booth(NWIN - 1, false, d, neg);
+            T tx, ty, tb;
+            u3_load<CU>(tx, ty, tb, row(d ? d : 1));
+            U<CU, 2, 4> sy;
+            u_select(sy, neg, u_neg(ty), u_as<2, 4>(ty));
+            q.x = tx;
+            q.y = u_reduce(sy);
+            q.z = u_as<UJac<CU>::ZK, UJac<CU>::ZV>(one);
+            if (d == 0) u_set_zero(q.z);
+            if constexpr (GLV) {
+              win = NWIN - 1;
+              sub = 6;  // the second half's addition of the top window comes next
+            } else {
+              win = NWIN - 2;
+              sub = 0;
+            }
           }
         } else if (sub < LAST_SUB) {
           ++sub;

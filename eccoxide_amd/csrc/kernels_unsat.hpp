@@ -401,7 +401,23 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_var_uns
           e.zz = u_fit<1, 3>(u_sqr(e.z));
           e.zzz = u_fit<1, 3>(u_mul(e.zz, e.z));
           uentry_store<CU>(row(b + 2), e);
-          if (++b == 15) u_set_zero(q.z);            // accumulator starts at infinity
+          if (++b == 15) {
+            // the top window has nothing to double and nothing to add to: the accumulator STARTS as
+            // its signed table entry (infinity for digit 0) and the loop goes on with the next window
+            uint32_t d;
+            bool neg;
+            booth(NWIN - 1, d, neg);
+            UEntry<CU> top;
+            uentry_load<CU>(top, row(d ? d : 1));
+            U<CU, 2, 4> sy;
+            u_select(sy, neg, u_neg(top.y), u_as<2, 4>(top.y));
+            q.x = top.x;
+            q.y = u_reduce(sy);
+            q.z = u_as<UJac<CU>::ZK, UJac<CU>::ZV>(top.z);
+            if (d == 0) u_set_zero(q.z);
+            win = NWIN - 2;
+            sub = 0;
+          }
         } else if (sub < 5) {
           ++sub;
         } else {

@@ -51,7 +51,8 @@ __device__ __forceinline__ uint32_t lanes_mont_mul(uint32_t a, uint32_t b, uint3
     spill += t < acc;                                                                               \
     acc = t;                                                                                        \
     /* divide by 2^32: lane j keeps its high word (+ spill) and takes the low word of lane j + 1 */ \
-    const uint32_t lo_up = (j == 7) ? 0u : from_up((uint32_t)acc);                                  \
+    const uint32_t up = from_up((uint32_t)acc); /* every lane executes the move: a DPP read of a */ \
+    const uint32_t lo_up = (j == 7) ? 0u : up;  /* lane masked off by EXEC returns nothing       */ \
     const uint64_t hi = (acc >> 32) | ((uint64_t)spill << 32);                                      \
     acc = hi + lo_up;                                                                               \
     spill = 0;                                                                                      \
