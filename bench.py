@@ -85,16 +85,16 @@ WORKLOADS = {
     # fixed base, default path: 16-bit windows, 16 additions of 7 products (Edwards, 81 + 9 mads each)
     # or of 8 products + 3 squares (P-256) on unsaturated limbs, then the saturated normalisation
     "ed25519_base_2^20": ("ed25519", "base", 1 << 20, 96,
-                          {"mad": (16 * 7 + 8) * (81 + 9), "pair": 0}),
+                          {"mad": (15 * 7 + 1 + 8) * (81 + 9), "pair": 0}),   # window 0 is loaded (1 product), 15 additions
     "p256r1_base_2^20": ("p256r1", "base", 1 << 20, 96,
-                         {"mad": 16 * (8 * (81 + 36) + 3 * (45 + 36)) + 9 * (81 + 36) + (45 + 36), "pair": 0}),
+                         {"mad": 15 * (8 * (81 + 36) + 3 * (45 + 36)) + 9 * (81 + 36) + (45 + 36), "pair": 0}),   # window 0 is loaded
     # unsaturated 9 x 29 ladder: per bit 5 products (81 + 9 mads), 4 squares (45 + 9), one small multiple (9 + 1)
     "p384r1_base_2^19": ("p384r1", "base", 1 << 19, 144,
-                         {"mad": 24 * (8 * 252 + 3 * 161) + 9 * 252 + 161, "pair": 0}),
+                         {"mad": 23 * (8 * 252 + 3 * 161) + 9 * 252 + 161, "pair": 0}),
     "p521r1_base_2^19": ("p521r1", "base", 1 << 19, 198,
-                         {"mad": 33 * (8 * 324 + 3 * 171) + 9 * 324 + 171, "pair": 0}),
+                         {"mad": 32 * (8 * 324 + 3 * 171) + 9 * 324 + 171, "pair": 0}),
     "bls12_381_g1_base_2^20": ("bls12_381_g1", "base", 1 << 20, 128,
-                               {"mad": 16 * (8 * 392 + 3 * 301) + 9 * 392 + 301, "pair": 0}),
+                               {"mad": 15 * (8 * 196 + 3 * 105 + 10 * 196) + 9 * 392 + 301, "pair": 0}),   # Y3 merged: 10 reductions per addition
     "x25519_2^20": ("ed25519", "x25519", 1 << 20, 96,
                     {"mad": 256 * (5 * 90 + 4 * 54 + 10) + 6 * 90, "pair": 0}),
     # edwards25519 variable base: 52 signed windows of 4 x (4 squares + 3 products) + (4 + 4) + a

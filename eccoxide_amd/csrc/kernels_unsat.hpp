@@ -248,7 +248,7 @@ ECCX_DEV uint32_t comb_digit(const uint8_t* __restrict__ k, int w) {
   if (b + 2 < SB) v |= (uint32_t)k[SB - 3 - b] << 16;
   return (v >> (pos & 7)) & ((1u << W) - 1u);
 }
-template <class CU>
+template <class CU, bool FROM_INFINITY = false>
 ECCX_DEV void ucomb_accumulate(UJac<CU>& q, const uint8_t* __restrict__ k, const uint32_t* __restrict__ table);
 
 // FUSED: the double-scalar "verify shape" u1*G + u2*Q (src/protocol/ecdsa.rs:215) in one pass:
@@ -426,7 +426,7 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_var_uns
         }
       }
     }
-    if constexpr (FUSED) ucomb_accumulate<CU>(q, base_scalars + idx * (size_t)SB, utable);
+    if constexpr (FUSED) ucomb_accumulate<CU, false>(q, base_scalars + idx * (size_t)SB, utable);
     if (active) {
       u3_store<CU>(rows_out + idx * (size_t)urow3_words<CU>(), q.x, q.y, u_fit<1, 3>(q.z));
       flags[idx] = rejected ? 2 : 0;
@@ -487,7 +487,9 @@ __global__ void k_affine_to_utable(size_t entries, const uint8_t* __restrict__ a
 // q += sum over the scalar's bytes of table[(w, byte)]: the comb loop shared by the fixed-base
 // kernel and the fused double-scalar kernel.  Jacobian mixed additions with the same special
 // cases as the variable-base ladder (accumulator at infinity, digit 0, q == -entry, q == entry).
-template <class CU>
+// FROM_INFINITY: q is the point at infinity on entry (the fixed-base kernel), so window 0 is LOADED
+// (the entry itself with Z = 1, or infinity for digit 0) instead of being added
+template <class CU, bool FROM_INFINITY>
 ECCX_DEV void ucomb_accumulate(UJac<CU>& q, const uint8_t* __restrict__ k, const uint32_t* __restrict__ table) {
   using CS = typename CU::Sat;
   constexpr int SB = CS::SB;
@@ -497,8 +499,8 @@ ECCX_DEV void ucomb_accumulate(UJac<CU>& q, const uint8_t* __restrict__ k, const
   U<CU, 1, 2> one;
 #pragma unroll
   for (int i = 0; i < CU::N; ++i) one.v[i] = CU::ONE[i];
-  for (int w = 0; w < NW; ++w) {
-    const uint32_t d = comb_digit<W, SB>(k, w);
+  auto entry = [&](int w, uint32_t& d, U<CU, 1, 2>& x2, U<CU, 1, 2>& y2) {
+    d = comb_digit<W, SB>(k, w);
     const uint4* __restrict__ e = reinterpret_cast<const uint4*>(table + (((size_t)w << W) + (d ? d : 1)) * UW);
     constexpr int LW = ((2 * CU::N + 3) / 4) * 4;  // words actually read (the rest of the entry is padding)
     uint32_t ew[LW];
@@ -507,9 +509,22 @@ ECCX_DEV void ucomb_accumulate(UJac<CU>& q, const uint8_t* __restrict__ k, const
       const uint4 v = e[i];
       ew[4 * i] = v.x; ew[4 * i + 1] = v.y; ew[4 * i + 2] = v.z; ew[4 * i + 3] = v.w;
     }
-    U<CU, 1, 2> x2, y2;
 #pragma unroll
     for (int i = 0; i < CU::N; ++i) { x2.v[i] = ew[i]; y2.v[i] = ew[CU::N + i]; }
+  };
+  if constexpr (FROM_INFINITY) {
+    uint32_t d;
+    U<CU, 1, 2> x2, y2;
+    entry(0, d, x2, y2);
+    q.x = u_as<1, 3>(x2);
+    q.y = u_as<1, 3>(y2);
+    q.z = u_as<UJac<CU>::ZK, UJac<CU>::ZV>(one);
+    if (d == 0) u_set_zero(q.z);
+  }
+  for (int w = FROM_INFINITY ? 1 : 0; w < NW; ++w) {
+    uint32_t d;
+    U<CU, 1, 2> x2, y2;
+    entry(w, d, x2, y2);
     const bool q_inf = u_limbs_all_zero(q.z);
     const bool e_skip = (d == 0);
     UJac<CU> sum;
@@ -558,7 +573,7 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_base_un
     q.x = u_as<1, 3>(one);
     q.y = u_as<1, 3>(one);
     u_set_zero(q.z);  // infinity
-    ucomb_accumulate<CU>(q, k, table);
+    ucomb_accumulate<CU, true>(q, k, table);
     if (active) {
       u3_store<CU>(rows_out + idx * (size_t)urow3_words<CU>(), q.x, q.y, u_fit<1, 3>(q.z));
       flags[idx] = 0;
@@ -683,13 +698,16 @@ ECCX_DEV void ued_add_niels(U<CU, 1, 3>& qx, U<CU, 1, 3>& qy, U<CU, 1, 3>& qz, U
   qt = u_fit<1, 3>(u_mul(e, h));
 }
 
-// q += sum over the 16-bit windows of k of table[(w, digit)] (complete additions)
-template <class CU>
+// q += sum over the 16-bit windows of k of table[(w, digit)] (complete additions).
+// FROM_NEUTRAL: q is the neutral element on entry, so window 0 is not added but LOADED: with
+// (ym, yp) = (y - x, y + x) the point (x, y) is (2(yp - ym) : 2(yp + ym) : 4 : (yp - ym)(yp + ym)) in
+// extended coordinates -- one product instead of the seven of an addition.
+template <class CU, bool FROM_NEUTRAL = false>
 ECCX_DEV void ued_comb_accumulate(U<CU, 1, 3>& qx, U<CU, 1, 3>& qy, U<CU, 1, 3>& qz, U<CU, 1, 3>& qt,
                                   const uint8_t* __restrict__ k, const uint32_t* __restrict__ table) {
   constexpr int N = CU::N;
   constexpr int W = comb_bits<CU>();
-  for (int w = 0; w < comb_windows<CU>(); ++w) {
+  auto entry = [&](int w, U<CU, 1, 3>& ym, U<CU, 1, 3>& yp, U<CU, 1, 3>& t2d) {
     const uint32_t d = comb_digit<W, 32>(k, w);  // the big-endian scalar string (curve25519.rs:842-846)
     const uint4* __restrict__ e4 = reinterpret_cast<const uint4*>(table + (((size_t)w << W) + d) * ED_U_ENTRY_WORDS);
     constexpr int LW = ((3 * N + 3) / 4) * 4;  // words actually read (the rest of the entry is padding)
@@ -699,9 +717,23 @@ ECCX_DEV void ued_comb_accumulate(U<CU, 1, 3>& qx, U<CU, 1, 3>& qy, U<CU, 1, 3>&
       const uint4 v = e4[i];
       ew[4 * i] = v.x; ew[4 * i + 1] = v.y; ew[4 * i + 2] = v.z; ew[4 * i + 3] = v.w;
     }
-    U<CU, 1, 3> ym, yp, t2d;
 #pragma unroll
     for (int i = 0; i < N; ++i) { ym.v[i] = ew[i]; yp.v[i] = ew[N + i]; t2d.v[i] = ew[2 * N + i]; }
+  };
+  if constexpr (FROM_NEUTRAL) {
+    U<CU, 1, 3> ym, yp, t2d;
+    entry(0, ym, yp, t2d);
+    const auto dx = u_reduce(u_sub(yp, ym));  // 2x
+    const auto sy = u_reduce(u_add(yp, ym));  // 2y
+    qx = u_reduce(u_add(dx, dx));
+    qy = u_reduce(u_add(sy, sy));
+    u_set_zero(qz);
+    qz.v[0] = 4;
+    qt = u_fit<1, 3>(u_mul(dx, sy));          // 4xy = X Y / Z
+  }
+  for (int w = FROM_NEUTRAL ? 1 : 0; w < comb_windows<CU>(); ++w) {
+    U<CU, 1, 3> ym, yp, t2d;
+    entry(w, ym, yp, t2d);
     ued_add_niels<CU>(qx, qy, qz, qt, ym, yp, t2d);
   }
 }
@@ -743,7 +775,7 @@ __global__ void __launch_bounds__(WG, 4) k_ed_scalarmul_base_unsat(size_t n, con
     T qx, qy, qz, qt;  // the neutral element (0, 1, 1, 0)
     u_set_zero(qx); u_set_zero(qy); u_set_zero(qz); u_set_zero(qt);
     qy.v[0] = 1; qz.v[0] = 1;
-    ued_comb_accumulate<CU>(qx, qy, qz, qt, k, table);
+    ued_comb_accumulate<CU, true>(qx, qy, qz, qt, k, table);
     if (active) {
       u3_store<CU>(rows_out + idx * (size_t)urow3_words<CU>(), qx, qy, qz);
       flags[idx] = 0;
