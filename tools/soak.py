@@ -76,6 +76,16 @@ def main():
         v_def, vf_def = eng.scalarmul_var_t(curve, k2, b_def)
         v_mir, vf_mir = eng.scalarmul_var_t(curve, k2, b_def, mirror=True)
         assert torch.equal(v_def, v_mir) and torch.equal(vf_def, vf_mir), ("var", curve, n, rounds)
+        if curve == "bls12_381_g1":
+            # the bases are multiples of G, so the endomorphism ladder must agree with the co-Z ladder
+            v_glv, vf_glv = eng.scalarmul_var_t(curve, k2, b_def, assume_subgroup=True)
+            assert torch.equal(v_glv, v_def) and torch.equal(vf_glv, vf_def), ("glv", curve, n, rounds)
+        if rounds % 6 == 0:
+            # ECCX_CT_SCAN: the mirror kernels with the scanning lookups
+            v_ct, vf_ct = eng.scalarmul_var_t(curve, k2, b_def, ct_scan=True)
+            assert torch.equal(v_ct, v_def) and torch.equal(vf_ct, vf_def), ("ct var", curve, n, rounds)
+            b_ct, f_ct = eng.scalarmul_base_t(curve, k1, ct_scan=True)
+            assert torch.equal(b_ct, b_mir) and torch.equal(f_ct, f_mir), ("ct base", curve, n, rounds)
         # fused double-scalar against comb + ladder + complete addition
         for subtract in (False, True):
             d_out, d_fl = eng.double_scalarmul_t(curve, k1, k2, b_def, subtract=subtract)
