@@ -41,6 +41,23 @@ int main() {
         return 1;
       }
     }
+    // secret-scalar mode (ECCX_CT_SCAN through the engine switch) gives the same points, and the
+    // one-time costs can be paid up front
+    {
+      eccx::Engine ct(0);
+      ct.prepare<C>(n);
+      if (ct.device_bytes() == 0) { std::puts("FAIL: prepare left the context empty"); return 1; }
+      ct.secret_scalars(true);
+      const auto& sb = eccx::Points<C>::mul_base(ct, scalars).to_affine();
+      const auto& sv = (eccx::on(ct, gen) * scalars).to_affine();
+      for (size_t i = 0; i < n; ++i) {
+        if (sb.is_infinity(i) != a.is_infinity(i) || std::memcmp(sb.x(i), a.x(i), 64) ||
+            sv.is_infinity(i) != a.is_infinity(i) || std::memcmp(sv.x(i), a.x(i), 64)) {
+          std::printf("FAIL: scanning kernels differ at %zu\n", i);
+          return 1;
+        }
+      }
+    }
     // CurveGroup::double and Add: 2*G == G + G == G.dbl(), and (k*G) - (k*G) is infinity
     auto two_g = gen.dbl(eng).to_affine();
     auto g_plus_g = gen.add(eng, gen).to_affine();
