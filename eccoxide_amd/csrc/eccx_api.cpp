@@ -9,7 +9,6 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
-#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -50,12 +49,6 @@ struct eccx_ctx {
   int cus = 0;
   hipStream_t stream = nullptr;
   hipStream_t in_stream = nullptr, out_stream = nullptr;  // host-buffer entry points: copies beside the compute
-  // fixed base in chunks: the latency-bound normalisation of chunk c runs on aux_stream beside the comb
-  // of chunk c + 1 (fork / join events keep the caller's stream order)
-  hipStream_t aux_stream = nullptr;
-  static constexpr int MAX_CHUNKS = 8;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_chunk[MAX_CHUNKS] = {};
-  int base_chunks = 1;
   uint32_t* comb[NCURVES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   uint32_t* comb_u[NCURVES] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // unsaturated-field copies
   uint32_t* comb_lds[NCURVES] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // images for the LDS variant
@@ -493,19 +486,6 @@ int eccx_init(int device, eccx_ctx** out_ctx) {
     delete ctx;
     return ECCX_ERR_HIP;
   }
-  bool ok = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) == hipSuccess &&
-            hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) == hipSuccess;
-  for (int i = 0; ok && i < eccx_ctx::MAX_CHUNKS; ++i)
-    ok = hipEventCreateWithFlags(&ctx->ev_chunk[i], hipEventDisableTiming) == hipSuccess;
-  if (!ok) {
-    eccx_shutdown(ctx);
-    return ECCX_ERR_HIP;
-  }
-  if (const char* e = std::getenv("ECCX_BASE_CHUNKS")) {  // A/B knob; see eccx_scalarmul_base_dev
-    const int c = std::atoi(e);
-    if (c >= 1 && c <= eccx_ctx::MAX_CHUNKS) ctx->base_chunks = c;
-  }
   *out_ctx = ctx;
   return ECCX_OK;
 }
@@ -525,14 +505,6 @@ void eccx_shutdown(eccx_ctx* ctx) {
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->in_stream) (void)hipStreamDestroy(ctx->in_stream);
   if (ctx->out_stream) (void)hipStreamDestroy(ctx->out_stream);
-  if (ctx->aux_stream) {
-    (void)hipStreamSynchronize(ctx->aux_stream);
-    (void)hipStreamDestroy(ctx->aux_stream);
-  }
-  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
-  for (auto& e : ctx->ev_chunk)
-    if (e) (void)hipEventDestroy(e);
   delete ctx;
 }
 
@@ -643,34 +615,6 @@ int eccx_scalarmul_base_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_sc
     rc = ensure_rows(ctx, ops, n);
     if (rc) return rc;
     const int ugrid = ops->var_fast_grid ? std::max(grid, ops->var_fast_grid(ctx->cus, n)) : grid;
-    const int chunks = (n >= ((size_t)1 << 18)) ? ctx->base_chunks : 1;
-    if (chunks > 1) {
-      // The normalisation is a latency-bound chain (one wavefront's 16 units and one inversion, ~0.1 ms
-      // whatever the batch): run it for chunk c on the auxiliary stream while the comb of chunk c + 1
-      // occupies the caller's stream.  Chunks are multiples of 4096 units; buffers are disjoint.
-      const size_t step = (((n + chunks - 1) / chunks) + 4095) / 4096 * 4096;
-      const size_t sb = (size_t)ops->info.sb, pb = 2 * (size_t)ops->info.fb, jw = (size_t)ops->info.jac_words;
-      int c = 0;  // (the auxiliary stream needs no fork event: each of its kernels waits for its chunk's comb)
-      for (size_t lo = 0; lo < n; lo += step, ++c) {
-        const size_t cnt = std::min(step, n - lo);
-        const size_t cneed = (cnt + eccx::LAUNCH_WG - 1) / eccx::LAUNCH_WG;
-        // leave room on every CU for the normalisation's wavefronts: 6 of the 8 workgroup slots
-        const int cgrid = (int)std::max<size_t>(1, std::min(cneed, (size_t)ctx->cus * 6));
-        HIP_TRY(ctx, ops->base_unsat(cgrid, s, cnt, static_cast<const uint8_t*>(d_scalars) + lo * sb, ctx->comb_u[curve],
-                                     ctx->jac + lo * jw, static_cast<uint8_t*>(d_flags) + lo));
-        const bool last = lo + step >= n;
-        hipStream_t ns = last ? s : ctx->aux_stream;
-        if (!last) {
-          HIP_TRY(ctx, hipEventRecord(ctx->ev_chunk[c], s));
-          HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_chunk[c], 0));
-        }
-        HIP_TRY(ctx, ops->to_affine_var(norm_grid(ctx, cnt), ns, cnt, ctx->jac + lo * jw,
-                                        static_cast<uint8_t*>(d_out) + lo * pb, static_cast<uint8_t*>(d_flags) + lo));
-      }
-      HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->aux_stream));
-      HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
-      return ECCX_OK;
-    }
     HIP_TRY(ctx, ops->base_unsat(ugrid, s, n, static_cast<const uint8_t*>(d_scalars), ctx->comb_u[curve], ctx->jac,
                                  static_cast<uint8_t*>(d_flags)));
     HIP_TRY(ctx, ops->to_affine_var(norm_grid(ctx, n), s, n, ctx->jac, static_cast<uint8_t*>(d_out),

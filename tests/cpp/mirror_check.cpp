@@ -48,8 +48,10 @@ int main() {
       ct.prepare<C>(n);
       if (ct.device_bytes() == 0) { std::puts("FAIL: prepare left the context empty"); return 1; }
       ct.secret_scalars(true);
-      const auto& sb = eccx::Points<C>::mul_base(ct, scalars).to_affine();
-      const auto& sv = (eccx::on(ct, gen) * scalars).to_affine();
+      auto sbase = eccx::Points<C>::mul_base(ct, scalars);
+      auto svar = eccx::on(ct, gen) * scalars;
+      const auto& sb = sbase.to_affine();
+      const auto& sv = svar.to_affine();
       for (size_t i = 0; i < n; ++i) {
         if (sb.is_infinity(i) != a.is_infinity(i) || std::memcmp(sb.x(i), a.x(i), 64) ||
             sv.is_infinity(i) != a.is_infinity(i) || std::memcmp(sv.x(i), a.x(i), 64)) {
