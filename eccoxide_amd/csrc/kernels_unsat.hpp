@@ -130,11 +130,17 @@ ECCX_DEV void ujac_dbl(UJac<CU>& r, const UJac<CU>& p) {
     auto x3a = u_sqr(alpha);                    // (1,2)
     auto x3 = u_reduce(u_sub(u_sub(x3a, b4), b4));    // alpha^2 - 8*beta  (5,10) -> (1,3)
     auto yz = u_mul(p.y, p.z);                  // (1,2)
-    auto g8s = u_sqr(g2);                       // 4*gamma^2          (1,2)
     auto t = u_sub(b4, x3);                     // (3,6)
-    auto y3m = u_mul(alpha, t);                 // (1,2)
     r.x = x3;
-    r.y = u_reduce(u_sub(u_sub(y3m, g8s), g8s));      // ... - 8*gamma^2   (5,10) -> (1,3)
+    if constexpr (UB<CU>::SPARSE) {
+      // signed columns (P-384): Y3 = alpha*t - 2*(2 gamma)^2 in ONE reduction -- the square's own
+      // reduction, its column extractions and the carry chain of the difference all go away
+      r.y = u_mul_sub_2sqr(alpha, t, g2);
+    } else {
+      auto g8s = u_sqr(g2);                     // 4*gamma^2          (1,2)
+      auto y3m = u_mul(alpha, t);               // (1,2)
+      r.y = u_reduce(u_sub(u_sub(y3m, g8s), g8s));    // ... - 8*gamma^2   (5,10) -> (1,3)
+    }
     r.z = u_fit<UJac<CU>::ZK, UJac<CU>::ZV>(u_add(yz, yz));  // 2*Y*Z      (2,4)
   }
 }
@@ -169,6 +175,8 @@ ECCX_DEV void ujac_add_raw(UJac<CU>& r, bool& h_zero, bool& r_zero, U<CU, 1, 3>&
     // Y3 = r*(v - x3) + (4p - s1)*h^3: two products, one reduction (the general Montgomery
     // reduction is half of every product there)
     r.y = u_fit<1, 3>(u_mul_add(rr, tt, u_neg(s1), hhh));
+  } else if constexpr (UB<CU>::SPARSE) {
+    r.y = u_mul_sub(rr, tt, s1, hhh);           // signed columns: r*(v - x3) - s1*h^3 in one reduction
   } else {
     auto y3a = u_mul(rr, tt);
     auto s1h = u_mul(s1, hhh);
@@ -456,6 +464,8 @@ ECCX_DEV void ujac_madd_raw(UJac<CU>& r, bool& h_zero, bool& r_zero, const UJac<
   r.x = x3;
   if constexpr (CU::KIND == UK_MONT) {
     r.y = u_fit<1, 3>(u_mul_add(rr, u_sub(v, x3), u_neg(p.y), hhh));  // one reduction for both products
+  } else if constexpr (UB<CU>::SPARSE) {
+    r.y = u_mul_sub(rr, u_sub(v, x3), p.y, hhh);
   } else {
     auto y3a = u_mul(rr, u_sub(v, x3));
     auto y1h = u_mul(p.y, hhh);

@@ -53,6 +53,11 @@ __device__ __forceinline__ void smad1_k(uint64_t& acc, uint32_t a, int32_t k) {
   asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "s"(k) : "vcc");
 }
 
+// acc += a * b, both signed 32-bit register operands
+__device__ __forceinline__ void smad1_v(uint64_t& acc, int32_t a, int32_t b) {
+  asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
+}
+
 enum : int { UK_MONT_PP1 = 0, UK_MONT = 1, UK_MERSENNE = 2, UK_PM19 = 3 };
 
 template <class C, int K, int V>
@@ -241,6 +246,73 @@ ECCX_DEV void u_mul2_core_mont(uint32_t (&r)[C::N], const uint32_t (&a)[C::N], c
     }
     acc >>= C::B;
   }
+  t[N - 1] = (uint32_t)acc;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r[i] = t[i];
+}
+
+// (a*b - c*d) / R + p, or (a*b - 2*c*c) / R + p with NEG_SQ, in ONE reduction, for the fields whose
+// Montgomery reduction runs on signed columns already (SPARSE: P-384).  The subtracted product is
+// accumulated with v_mad_i64_i32 against negated limbs (as a square: cross terms once, against the
+// doubled operand), p comes in through its sparse form p = (p + 1) - 1 added to the columns above R, so
+// the result is positive whatever the operands.  Both sides of a column stay inside 63 bits as long as
+// each product's K1*K2 is within KKMAX (the bound already leaves room for the reduction's terms).
+template <class C, bool NEG_SQ>
+ECCX_DEV void u_mul_sub_core_sparse(uint32_t (&r)[C::N], const uint32_t (&a)[C::N], const uint32_t (&b)[C::N],
+                                    const uint32_t (&c)[C::N], const uint32_t (&d)[C::N]) {
+  constexpr int N = C::N;
+  static_assert(C::KIND == UK_MONT_PP1 && C::SPARSE_N > 0, "signed columns: the sparse Montgomery fields");
+  uint32_t m[N], t[N];
+  int32_t nc[N];  // -c (NEG_SQ: -2c)
+#pragma unroll
+  for (int i = 0; i < N; ++i) nc[i] = NEG_SQ ? -(int32_t)(c[i] << 1) : -(int32_t)c[i];
+  // p = (p + 1) - 1 as what it adds to result digit j (column N + j)
+  auto offset = [](int j) constexpr -> int64_t {
+    int64_t v = (j == 0) ? -1 : 0;
+    for (int tm = 0; tm < C::SPARSE_N; ++tm)
+      if (C::SPARSE_OFF[tm] == j) v += (int64_t)C::SPARSE_SIGN[tm] * ((int64_t)1 << C::SPARSE_SHIFT[tm]);
+    return v;
+  };
+  uint64_t acc = 0;
+  UMacQ<false> qa;
+  UMacQ<true> qm;
+#pragma unroll
+  for (int k = 0; k < 2 * N - 1; ++k) {
+    const int lo = k < N ? 0 : k - N + 1, hi = k < N ? k : N - 1;
+    if (k >= N && offset(k - N) != 0) acc = (uint64_t)((int64_t)acc + offset(k - N));
+#pragma unroll
+    for (int i = lo; i <= hi; ++i) qa.push(acc, a[i], b[k - i]);
+    qa.flush(acc);
+    if constexpr (NEG_SQ) {
+      // -2 c^2: i < j terms once against 2c (nc = -2c, so nc_i * c_j * 2 = nc_i * (2 c_j)); diagonal nc_i * c_i
+#pragma unroll
+      for (int i = lo; 2 * i < k; ++i) smad1_v(acc, nc[i], (int32_t)(c[k - i] << 1));
+      if ((k & 1) == 0) smad1_v(acc, nc[k / 2], (int32_t)c[k / 2]);
+    } else {
+#pragma unroll
+      for (int i = lo; i <= hi; ++i) smad1_v(acc, nc[i], (int32_t)d[k - i]);
+    }
+    // m*(p+1) as signed shifted copies of m (as u_mul_core_mont)
+#pragma unroll
+    for (int tm = 0; tm < C::SPARSE_N; ++tm) {
+      const int i = k - C::SPARSE_OFF[tm];
+      if (i >= lo && i <= (k < N ? k - 1 : N - 1)) {
+        if (C::SPARSE_SIGN[tm] > 0) qm.push(acc, m[i], 1u << C::SPARSE_SHIFT[tm]);
+      }
+    }
+    qm.flush(acc);
+#pragma unroll
+    for (int tm = 0; tm < C::SPARSE_N; ++tm) {
+      const int i = k - C::SPARSE_OFF[tm];
+      if (i >= lo && i <= (k < N ? k - 1 : N - 1)) {
+        if (C::SPARSE_SIGN[tm] < 0) smad1_k(acc, m[i], -(int32_t)(1u << C::SPARSE_SHIFT[tm]));
+      }
+    }
+    if (k < N) m[k] = (uint32_t)acc & C::MASK;
+    else t[k - N] = (uint32_t)acc & C::MASK;
+    acc = (uint64_t)((int64_t)acc >> C::B);
+  }
+  if (offset(N - 1) != 0) acc = (uint64_t)((int64_t)acc + offset(N - 1));
   t[N - 1] = (uint32_t)acc;
 #pragma unroll
   for (int i = 0; i < N; ++i) r[i] = t[i];
@@ -481,6 +553,29 @@ ECCX_DEV auto u_mul_add(const U<C, K1, V1>& a, const U<C, K2, V2>& b, const U<C,
   static_assert(VO <= 3, "result too large: reduce an operand first");
   U<C, 1, VO> r;
   u_mul2_core_mont<C>(r.v, a.v, b.v, c.v, d.v);
+  return r;
+}
+
+// a*b - c*d (+ p) with one reduction, sparse Montgomery fields (P-384); K bounds per product
+template <class C, int K1, int V1, int K2, int V2, int K3, int V3, int K4, int V4>
+ECCX_DEV auto u_mul_sub(const U<C, K1, V1>& a, const U<C, K2, V2>& b, const U<C, K3, V3>& c, const U<C, K4, V4>& d) {
+  static_assert(UB<C>::SPARSE, "implemented for the sparse (signed-column) Montgomery fields");
+  static_assert(K1 * K2 <= UB<C>::KKMAX && K3 * K4 <= UB<C>::KKMAX, "a product overflows the signed columns");
+  static_assert(K3 <= 7 && K4 <= 7, "negated / signed operands must stay below 2^31");
+  static_assert((uint32_t)(V1 * V2) < C::RP && (uint32_t)(V3 * V4) < C::RP, "result outside (0, 3p)");
+  U<C, 1, 3> r;
+  u_mul_sub_core_sparse<C, false>(r.v, a.v, b.v, c.v, d.v);
+  return r;
+}
+// a*b - 2*c^2 (+ p) with one reduction
+template <class C, int K1, int V1, int K2, int V2, int K3, int V3>
+ECCX_DEV auto u_mul_sub_2sqr(const U<C, K1, V1>& a, const U<C, K2, V2>& b, const U<C, K3, V3>& c) {
+  static_assert(UB<C>::SPARSE, "implemented for the sparse (signed-column) Montgomery fields");
+  static_assert(K1 * K2 <= UB<C>::KKMAX && 2 * K3 * K3 <= UB<C>::KKMAX, "a product overflows the signed columns");
+  static_assert(2 * K3 <= 7, "doubled / negated operands must stay below 2^31");
+  static_assert((uint32_t)(V1 * V2) < C::RP && (uint32_t)(2 * V3 * V3) < C::RP, "result outside (0, 3p)");
+  U<C, 1, 3> r;
+  u_mul_sub_core_sparse<C, true>(r.v, a.v, b.v, c.v, c.v);
   return r;
 }
 

@@ -23,7 +23,13 @@ struct Chk {
 };
 
 enum : int { OP_MUL_TIGHT = 0, OP_MUL_LAZY = 1, OP_SQR_LAZY = 2, OP_SUB_CHAIN = 3, OP_REDUCE_MAX = 4,
-             OP_CANONICAL = 5, OP_MUL_AUTO = 6, OP_ADD_AUTO = 7, OP_REDUCE_LAZY = 8, OP_INVERT = 9 };
+             OP_CANONICAL = 5, OP_MUL_AUTO = 6, OP_ADD_AUTO = 7, OP_REDUCE_LAZY = 8, OP_INVERT = 9,
+             // merged products, four operands (a, b, c, d): one Montgomery reduction for two products
+             OP_MUL_ADD = 10,       // general Montgomery (BLS12-381): a*b + (4p - c)*d, tight c
+             OP_MUL_ADD_MAX = 11,   //   a*b + c*d at the column budget (K 3*3 + 2*4 = 17)
+             OP_MUL_SUB = 12,       // sparse signed columns (P-384): a*b - c*d (+ p)
+             OP_MUL_SUB_MAX = 13,   //   both products at the column budget (K 2*4 each)
+             OP_MUL_SUB_2SQR = 14 };//   a*b - 2*c^2 (+ p), the doubling's Y3
 
 template <class C, int K, int V>
 __device__ U<C, K, V> load_u(const uint32_t* p) {
@@ -40,15 +46,38 @@ __device__ void store_u(uint32_t* p, const U<C, K, V>& a) {
 
 template <class C>
 __global__ void k_field_check(int op, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
-                              uint32_t* __restrict__ out, size_t n) {
+                              uint32_t* __restrict__ out, size_t n, const uint32_t* __restrict__ c = nullptr,
+                              const uint32_t* __restrict__ d = nullptr) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   constexpr int N = C::N;
   constexpr int KM = UB<C>::KMAX;
   const uint32_t* pa = a + i * N;
   const uint32_t* pb = b + i * N;
+  const uint32_t* pc = c ? c + i * N : pa;
+  const uint32_t* pd = d ? d + i * N : pb;
   uint32_t* po = out + i * N;
   switch (op) {
+    case OP_MUL_ADD:
+      if constexpr (C::KIND == UK_MONT)
+        store_u(po, u_mul_add(load_u<C, 1, 3>(pa), load_u<C, 3, 6>(pb), u_neg(load_u<C, 1, 3>(pc)), load_u<C, 1, 3>(pd)));
+      break;
+    case OP_MUL_ADD_MAX:
+      if constexpr (C::KIND == UK_MONT)
+        store_u(po, u_mul_add(load_u<C, 3, 6>(pa), load_u<C, 3, 6>(pb), load_u<C, 2, 4>(pc), load_u<C, 4, 8>(pd)));
+      break;
+    case OP_MUL_SUB:
+      if constexpr (UB<C>::SPARSE)
+        store_u(po, u_mul_sub(load_u<C, 1, 3>(pa), load_u<C, 3, 6>(pb), load_u<C, 1, 3>(pc), load_u<C, 1, 3>(pd)));
+      break;
+    case OP_MUL_SUB_MAX:
+      if constexpr (UB<C>::SPARSE)
+        store_u(po, u_mul_sub(load_u<C, 2, 4>(pa), load_u<C, 4, 8>(pb), load_u<C, 2, 4>(pc), load_u<C, 4, 8>(pd)));
+      break;
+    case OP_MUL_SUB_2SQR:
+      if constexpr (UB<C>::SPARSE)
+        store_u(po, u_mul_sub_2sqr(load_u<C, 2, 4>(pa), load_u<C, 4, 8>(pb), load_u<C, 2, 4>(pc)));
+      break;
     case OP_MUL_TIGHT: store_u(po, u_mul(load_u<C, 1, 3>(pa), load_u<C, 1, 3>(pb))); break;
     case OP_MUL_LAZY:
       store_u(po, u_mul(load_u<C, Chk<C>::KA, Chk<C>::VA>(pa), load_u<C, Chk<C>::KB, Chk<C>::VB>(pb)));
@@ -117,28 +146,43 @@ int fieldcheck_info(int curve, int* info) {
 #undef ECCX_INFO
 }
 
+int fieldcheck_run4(int curve, int op, const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d,
+                    uint32_t* out, size_t n);
 // runs one operation over n rows of N limbs (host pointers); returns 0 or a hipError_t
 int fieldcheck_run(int curve, int op, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t n) {
+  return fieldcheck_run4(curve, op, a, b, nullptr, nullptr, out, n);
+}
+// the same with two more operand arrays (merged products); c / d may be null
+int fieldcheck_run4(int curve, int op, const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d,
+                    uint32_t* out, size_t n) {
   using namespace eccx;
   int info[8];
   if (fieldcheck_info(curve, info)) return -1;
   const size_t bytes = n * (size_t)info[0] * sizeof(uint32_t);
-  uint32_t *da = nullptr, *db = nullptr, *dout = nullptr;
+  uint32_t *da = nullptr, *db = nullptr, *dout = nullptr, *dc = nullptr, *dd = nullptr;
   hipError_t e;
   if ((e = hipMalloc(&da, bytes)) != hipSuccess) return (int)e;
   if ((e = hipMalloc(&db, bytes)) != hipSuccess) { (void)hipFree(da); return (int)e; }
   if ((e = hipMalloc(&dout, bytes)) != hipSuccess) { (void)hipFree(da); (void)hipFree(db); return (int)e; }
+  if (c && d) {
+    if ((e = hipMalloc(&dc, bytes)) != hipSuccess || (e = hipMalloc(&dd, bytes)) != hipSuccess) {
+      (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout); if (dc) (void)hipFree(dc);
+      return (int)e;
+    }
+    (void)hipMemcpy(dc, c, bytes, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dd, d, bytes, hipMemcpyHostToDevice);
+  }
   (void)hipMemcpy(da, a, bytes, hipMemcpyHostToDevice);
   (void)hipMemcpy(db, b, bytes, hipMemcpyHostToDevice);
   (void)hipMemset(dout, 0, bytes);
   const int wg = 128;
   const int grid = (int)((n + wg - 1) / wg);
   switch (curve) {
-    case 0: hipLaunchKernelGGL(k_field_check<P256U>, dim3(grid), dim3(wg), 0, 0, op, da, db, dout, n); break;
-    case 1: hipLaunchKernelGGL(k_field_check<P384U>, dim3(grid), dim3(wg), 0, 0, op, da, db, dout, n); break;
-    case 2: hipLaunchKernelGGL(k_field_check<P521U>, dim3(grid), dim3(wg), 0, 0, op, da, db, dout, n); break;
-    case 3: hipLaunchKernelGGL(k_field_check<BLS12_381U>, dim3(grid), dim3(wg), 0, 0, op, da, db, dout, n); break;
-    case 4: hipLaunchKernelGGL(k_field_check<ED25519U>, dim3(grid), dim3(wg), 0, 0, op, da, db, dout, n); break;
+    case 0: hipLaunchKernelGGL(k_field_check<P256U>, dim3(grid), dim3(wg), 0, 0, op, da, db, dout, n, dc, dd); break;
+    case 1: hipLaunchKernelGGL(k_field_check<P384U>, dim3(grid), dim3(wg), 0, 0, op, da, db, dout, n, dc, dd); break;
+    case 2: hipLaunchKernelGGL(k_field_check<P521U>, dim3(grid), dim3(wg), 0, 0, op, da, db, dout, n, dc, dd); break;
+    case 3: hipLaunchKernelGGL(k_field_check<BLS12_381U>, dim3(grid), dim3(wg), 0, 0, op, da, db, dout, n, dc, dd); break;
+    case 4: hipLaunchKernelGGL(k_field_check<ED25519U>, dim3(grid), dim3(wg), 0, 0, op, da, db, dout, n, dc, dd); break;
     default: break;
   }
   e = hipGetLastError();
@@ -147,6 +191,8 @@ int fieldcheck_run(int curve, int op, const uint32_t* a, const uint32_t* b, uint
   (void)hipFree(da);
   (void)hipFree(db);
   (void)hipFree(dout);
+  if (dc) (void)hipFree(dc);
+  if (dd) (void)hipFree(dd);
   return (int)e;
 }
 }

@@ -28,6 +28,7 @@ P = {
 }
 NAMES = {0: "p256r1", 1: "p384r1", 2: "p521r1", 3: "bls12_381_g1", 4: "curve25519"}
 OP_MUL_TIGHT, OP_MUL_LAZY, OP_SQR_LAZY, OP_SUB_CHAIN, OP_REDUCE_MAX, OP_CANONICAL, OP_MUL_AUTO, OP_ADD_AUTO, OP_REDUCE_LAZY, OP_INVERT = range(10)
+OP_MUL_ADD, OP_MUL_ADD_MAX, OP_MUL_SUB, OP_MUL_SUB_MAX, OP_MUL_SUB_2SQR = range(10, 15)
 
 
 class FieldCheck:
@@ -43,6 +44,14 @@ class FieldCheck:
         arr = (ctypes.c_int * 8)()
         assert self.lib.fieldcheck_info(curve, arr) == 0
         return dict(zip(["N", "B", "KMAX", "KKMAX", "KA", "KB", "KS", "L"], list(arr)))
+
+    def run4(self, curve, op, a, b, c, d):
+        arrs = [np.ascontiguousarray(x, dtype=np.uint32) for x in (a, b, c, d)]
+        out = np.zeros_like(arrs[0])
+        self.lib.fieldcheck_run4.argtypes = [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_size_t]
+        rc = self.lib.fieldcheck_run4(curve, op, *[x.ctypes.data for x in arrs], out.ctypes.data, arrs[0].shape[0])
+        assert rc == 0, f"fieldcheck_run4 failed: hip error {rc}"
+        return out
 
     def run(self, curve, op, a, b):
         a = np.ascontiguousarray(a, dtype=np.uint32)
@@ -199,3 +208,55 @@ def test_division_step_inversion(fc, curve):
         got = sum(int(x) << (32 * i) for i, x in enumerate(ro[:L]))
         assert got < p
         assert got == (pow(v, -1, p) if v else 0), hex(v)
+
+
+@pytest.mark.gpu
+def test_merged_products_at_the_operand_bounds(fc):
+    """One Montgomery reduction for two products (round 2): u_mul_add on the general Montgomery field
+    (BLS12-381: unsigned columns, the subtraction as (4p - c)*d) and u_mul_sub / u_mul_sub_2sqr on the
+    sparse signed columns of P-384, with the worst limbs their column budgets admit -- every limb at
+    K*2^B - 1 on both sides, zero against maximal (the most negative columns), digits of p and 2p."""
+    rng = random.Random(500)
+    n = 768
+    # bls12_381: curve 3
+    inf, p = fc.info(3), P[3]
+    rinv = pow(mont_factor(3, inf), -1, p)
+    B = inf["B"]
+    a, b = gen(rng, inf, p, 1, 3, n), gen(rng, inf, p, 3, 6, n)
+    c, d = gen(rng, inf, p, 1, 3, n), gen(rng, inf, p, 1, 3, n)
+    for x in (b, c, d):
+        rng.shuffle(x)
+    out = fc.run4(3, OP_MUL_ADD, a, b, c, d)
+    for ra, rb, rc, rd, ro in zip(a, b, c, d, out):
+        check_out(ro, inf, p, (value(ra, B) * value(rb, B) - value(rc, B) * value(rd, B)) * rinv)
+    a, b = gen(rng, inf, p, 3, 6, n), gen(rng, inf, p, 3, 6, n)
+    c, d = gen(rng, inf, p, 2, 4, n), gen(rng, inf, p, 4, 8, n)
+    for x in (b, d):
+        rng.shuffle(x)
+    out = fc.run4(3, OP_MUL_ADD_MAX, a, b, c, d)
+    for ra, rb, rc, rd, ro in zip(a, b, c, d, out):
+        check_out(ro, inf, p, (value(ra, B) * value(rb, B) + value(rc, B) * value(rd, B)) * rinv)
+    # p384r1: curve 1
+    inf, p = fc.info(1), P[1]
+    rinv = pow(mont_factor(1, inf), -1, p)
+    B = inf["B"]
+    for op, ka, kb, kc, kd in ((OP_MUL_SUB, (1, 3), (3, 6), (1, 3), (1, 3)), (OP_MUL_SUB_MAX, (2, 4), (4, 8), (2, 4), (4, 8))):
+        for order in range(3):
+            a, b = gen(rng, inf, p, ka[0], ka[1], n), gen(rng, inf, p, kb[0], kb[1], n)
+            c, d = gen(rng, inf, p, kc[0], kc[1], n), gen(rng, inf, p, kd[0], kd[1], n)
+            if order == 1:      # extremes of a*b against shuffled c*d, and the other way round
+                rng.shuffle(c), rng.shuffle(d)
+            elif order == 2:
+                rng.shuffle(a), rng.shuffle(b)
+            out = fc.run4(1, op, a, b, c, d)
+            for ra, rb, rc, rd, ro in zip(a, b, c, d, out):
+                check_out(ro, inf, p, (value(ra, B) * value(rb, B) - value(rc, B) * value(rd, B)) * rinv)
+    for order in range(3):
+        a, b, c = gen(rng, inf, p, 2, 4, n), gen(rng, inf, p, 4, 8, n), gen(rng, inf, p, 2, 4, n)
+        if order == 1:
+            rng.shuffle(c)
+        elif order == 2:
+            rng.shuffle(a), rng.shuffle(b)
+        out = fc.run4(1, OP_MUL_SUB_2SQR, a, b, c, c)
+        for ra, rb, rc, ro in zip(a, b, c, out):
+            check_out(ro, inf, p, (value(ra, B) * value(rb, B) - 2 * value(rc, B) ** 2) * rinv)
