@@ -53,7 +53,7 @@ def _var_unsat(n, nz, sb, a0, inv, sat_pairs, mont=True, norm_u=8, glv_bits=0, m
     a = -3: doubling 4 products + 4 squares, addition 11 + 3 (Jacobian entries with cached Z^2, Z^3);
     window table: even entries by doubling, odd ones by addition (8 doublings + 7 additions), Z^2 and
     Z^3 per entry; ceil((8*sb + 1)/5) signed windows of 5 doublings + 1 addition.
-    a = 0 (BLS12-381): doubling 2 + 5; co-Z table (1 doubling + 14 mixed additions, then 4 products +
+    a = 0 (BLS12-381): doubling 3 products + 4 squares with 6 reductions (Y3 merged on signed columns); co-Z table (1 doubling + 14 mixed additions, then 4 products +
     1 square per entry), mixed additions of 8 products + 3 squares with 10 reductions (Y3 merged);
     merged_y3 (P-384): Y3 = alpha t - 2 (2 gamma)^2 and r (v - x3) - s1 h^3 take one reduction each.
     glv_bits > 0: the endomorphism form, two half-length scalars, 2 additions per window and one more
@@ -69,7 +69,7 @@ def _var_unsat(n, nz, sb, a0, inv, sat_pairs, mont=True, norm_u=8, glv_bits=0, m
     if a0:
         bits = glv_bits if glv_bits else 8 * sb
         nwin = (bits + 1 + 4) // 5
-        dbl, madd = cost(2, 5), cost(8, 3, 10)
+        dbl, madd = cost(3, 4, 6) + 0, cost(8, 3, 10)   # doubling: X*B, E*t, Y*Z + X^2, Y^2, E^2 and -2(2B)^2 as a square; 6 reductions
         per_entry = cost(4, 1) + (cost(1, 0) if glv_bits else 0)
         total = dbl + 14 * madd + 15 * per_entry + (cost(1, 0) if glv_bits else 0)   # (+ beta x of entry 16)
         total += (nwin - 1) * 5 * dbl + (nwin * (2 if glv_bits else 1) - 1) * madd + cost(1, 0)   # the top window's first entry is loaded, not added

@@ -80,7 +80,23 @@ ECCX_DEV void u3_load(U<CU, 1, 3>& x, U<CU, 1, 3>& y, U<CU, 1, 3>& z, const uint
 // beyond the three written out.
 template <class CU>
 ECCX_DEV void ujac_dbl(UJac<CU>& r, const UJac<CU>& p) {
-  if constexpr (CU::Sat::A0) {
+  if constexpr (CU::Sat::A0 && CU::KIND == UK_MONT) {
+    // a = 0 on a general Montgomery field (BLS12-381), where a reduction is half of every product:
+    // D = 4 X Y^2 as a product, and Y3 = E (D - X3) - 2 (2 Y^2)^2 in ONE reduction on signed columns
+    // (u_mul_sub_2sqr) -- 3 products + 4 squares with 6 reductions instead of 2 + 5 with 7
+    auto a = u_sqr(p.x);                                  // A = X^2
+    auto b = u_sqr(p.y);                                  // B = Y^2
+    auto xb = u_mul(p.x, b);
+    auto xb2 = u_add(xb, xb);
+    auto d = u_reduce(u_add(xb2, xb2));                   // D = 4 X B
+    auto e = u_reduce(u_add(u_add(a, a), a));             // E = 3 A
+    auto f = u_sqr(e);
+    auto x3 = u_reduce(u_sub(u_sub(f, d), d));            // X3 = E^2 - 2 D
+    auto yz = u_mul(p.y, p.z);
+    r.x = x3;
+    r.y = u_mul_sub_2sqr(e, u_sub(d, x3), u_add(b, b));   // E (D - X3) - 8 B^2
+    r.z = u_fit<UJac<CU>::ZK, UJac<CU>::ZV>(u_add(yz, yz));
+  } else if constexpr (CU::Sat::A0) {
     auto a = u_sqr(p.x);
     auto b = u_sqr(p.y);
     auto c = u_sqr(b);

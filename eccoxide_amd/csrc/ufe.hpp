@@ -318,6 +318,55 @@ ECCX_DEV void u_mul_sub_core_sparse(uint32_t (&r)[C::N], const uint32_t (&a)[C::
   for (int i = 0; i < N; ++i) r[i] = t[i];
 }
 
+// The same for the general Montgomery fields (BLS12-381), whose columns are unsigned in the plain
+// product: here they are read as signed -- 63 bits, K1*K2 <= KKS on each side -- and p enters as its
+// digits added to the columns above R.
+template <class C, bool NEG_SQ>
+ECCX_DEV void u_mul_sub_core_mont(uint32_t (&r)[C::N], const uint32_t (&a)[C::N], const uint32_t (&b)[C::N],
+                                  const uint32_t (&c)[C::N], const uint32_t (&d)[C::N]) {
+  constexpr int N = C::N;
+  static_assert(C::KIND == UK_MONT, "general Montgomery fields");
+  uint32_t m[N], t[N];
+  int32_t nc[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) nc[i] = NEG_SQ ? -(int32_t)(c[i] << 1) : -(int32_t)c[i];
+  uint64_t acc = 0;
+  UMacQ<false> qa;
+  UMacQ<true> qm;
+#pragma unroll
+  for (int k = 0; k < 2 * N - 1; ++k) {
+    const int lo = k < N ? 0 : k - N + 1, hi = k < N ? k : N - 1;
+    if (k >= N) acc += (uint64_t)C::P[k - N];  // + p*R
+#pragma unroll
+    for (int i = lo; i <= hi; ++i) qa.push(acc, a[i], b[k - i]);
+    qa.flush(acc);
+    if constexpr (NEG_SQ) {
+#pragma unroll
+      for (int i = lo; 2 * i < k; ++i) smad1_v(acc, nc[i], (int32_t)(c[k - i] << 1));
+      if ((k & 1) == 0) smad1_v(acc, nc[k / 2], (int32_t)c[k / 2]);
+    } else {
+#pragma unroll
+      for (int i = lo; i <= hi; ++i) smad1_v(acc, nc[i], (int32_t)d[k - i]);
+    }
+#pragma unroll
+    for (int i = lo; i <= (k < N ? k - 1 : N - 1); ++i) {
+      if (C::P[k - i] != 0) qm.push(acc, m[i], C::P[k - i]);
+    }
+    qm.flush(acc);
+    if (k < N) {
+      m[k] = ((uint32_t)acc * C::N0B) & C::MASK;
+      umad1_k(acc, m[k], C::P[0]);
+    } else {
+      t[k - N] = (uint32_t)acc & C::MASK;
+    }
+    acc = (uint64_t)((int64_t)acc >> C::B);
+  }
+  acc += (uint64_t)C::P[N - 1];
+  t[N - 1] = (uint32_t)acc;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r[i] = t[i];
+}
+
 // Mersenne product / square (kind 2), p = 2^k - 1 with B*N - k = S: the product's upper half
 // has weight 2^(B*N) = 2^S (mod p), so a_i * b_j with i + j >= N is accumulated into column
 // i + j - N times 2^S.  Inputs tight; output tight (digit 1 may exceed 2^B by the last carry).
@@ -556,26 +605,36 @@ ECCX_DEV auto u_mul_add(const U<C, K1, V1>& a, const U<C, K2, V2>& b, const U<C,
   return r;
 }
 
-// a*b - c*d (+ p) with one reduction, sparse Montgomery fields (P-384); K bounds per product
+// Signed-column budget of the merged differences: K1*K2 a product may have on either side of a column
+// (63 bits; one product's worth is left for the reduction's terms)
+template <class C>
+struct UBS {
+  static constexpr bool OK = UB<C>::SPARSE || C::KIND == UK_MONT;
+  static constexpr int KKS = (int)((~(uint64_t)0 >> 1) / ((uint64_t)C::N * UB<C>::COL)) - 1;
+};
+
+// a*b - c*d (+ p) with one reduction: sparse (P-384) and general (BLS12-381) Montgomery fields
 template <class C, int K1, int V1, int K2, int V2, int K3, int V3, int K4, int V4>
 ECCX_DEV auto u_mul_sub(const U<C, K1, V1>& a, const U<C, K2, V2>& b, const U<C, K3, V3>& c, const U<C, K4, V4>& d) {
-  static_assert(UB<C>::SPARSE, "implemented for the sparse (signed-column) Montgomery fields");
-  static_assert(K1 * K2 <= UB<C>::KKMAX && K3 * K4 <= UB<C>::KKMAX, "a product overflows the signed columns");
+  static_assert(UBS<C>::OK, "implemented for the Montgomery fields with room for signed columns");
+  static_assert(K1 * K2 <= UBS<C>::KKS && K3 * K4 <= UBS<C>::KKS, "a product overflows the signed columns");
   static_assert(K3 <= 7 && K4 <= 7, "negated / signed operands must stay below 2^31");
   static_assert((uint32_t)(V1 * V2) < C::RP && (uint32_t)(V3 * V4) < C::RP, "result outside (0, 3p)");
   U<C, 1, 3> r;
-  u_mul_sub_core_sparse<C, false>(r.v, a.v, b.v, c.v, d.v);
+  if constexpr (UB<C>::SPARSE) u_mul_sub_core_sparse<C, false>(r.v, a.v, b.v, c.v, d.v);
+  else u_mul_sub_core_mont<C, false>(r.v, a.v, b.v, c.v, d.v);
   return r;
 }
 // a*b - 2*c^2 (+ p) with one reduction
 template <class C, int K1, int V1, int K2, int V2, int K3, int V3>
 ECCX_DEV auto u_mul_sub_2sqr(const U<C, K1, V1>& a, const U<C, K2, V2>& b, const U<C, K3, V3>& c) {
-  static_assert(UB<C>::SPARSE, "implemented for the sparse (signed-column) Montgomery fields");
-  static_assert(K1 * K2 <= UB<C>::KKMAX && 2 * K3 * K3 <= UB<C>::KKMAX, "a product overflows the signed columns");
+  static_assert(UBS<C>::OK, "implemented for the Montgomery fields with room for signed columns");
+  static_assert(K1 * K2 <= UBS<C>::KKS && 2 * K3 * K3 <= UBS<C>::KKS, "a product overflows the signed columns");
   static_assert(2 * K3 <= 7, "doubled / negated operands must stay below 2^31");
   static_assert((uint32_t)(V1 * V2) < C::RP && (uint32_t)(2 * V3 * V3) < C::RP, "result outside (0, 3p)");
   U<C, 1, 3> r;
-  u_mul_sub_core_sparse<C, true>(r.v, a.v, b.v, c.v, c.v);
+  if constexpr (UB<C>::SPARSE) u_mul_sub_core_sparse<C, true>(r.v, a.v, b.v, c.v, c.v);
+  else u_mul_sub_core_mont<C, true>(r.v, a.v, b.v, c.v, c.v);
   return r;
 }
 

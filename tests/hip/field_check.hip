@@ -27,7 +27,7 @@ enum : int { OP_MUL_TIGHT = 0, OP_MUL_LAZY = 1, OP_SQR_LAZY = 2, OP_SUB_CHAIN = 
              // merged products, four operands (a, b, c, d): one Montgomery reduction for two products
              OP_MUL_ADD = 10,       // general Montgomery (BLS12-381): a*b + (4p - c)*d, tight c
              OP_MUL_ADD_MAX = 11,   //   a*b + c*d at the column budget (K 3*3 + 2*4 = 17)
-             OP_MUL_SUB = 12,       // sparse signed columns (P-384): a*b - c*d (+ p)
+             OP_MUL_SUB = 12,       // signed columns (P-384 sparse, BLS12-381 general): a*b - c*d (+ p)
              OP_MUL_SUB_MAX = 13,   //   both products at the column budget (K 2*4 each)
              OP_MUL_SUB_2SQR = 14 };//   a*b - 2*c^2 (+ p), the doubling's Y3
 
@@ -67,15 +67,15 @@ __global__ void k_field_check(int op, const uint32_t* __restrict__ a, const uint
         store_u(po, u_mul_add(load_u<C, 3, 6>(pa), load_u<C, 3, 6>(pb), load_u<C, 2, 4>(pc), load_u<C, 4, 8>(pd)));
       break;
     case OP_MUL_SUB:
-      if constexpr (UB<C>::SPARSE)
+      if constexpr (UBS<C>::OK)
         store_u(po, u_mul_sub(load_u<C, 1, 3>(pa), load_u<C, 3, 6>(pb), load_u<C, 1, 3>(pc), load_u<C, 1, 3>(pd)));
       break;
     case OP_MUL_SUB_MAX:
-      if constexpr (UB<C>::SPARSE)
+      if constexpr (UBS<C>::OK)
         store_u(po, u_mul_sub(load_u<C, 2, 4>(pa), load_u<C, 4, 8>(pb), load_u<C, 2, 4>(pc), load_u<C, 4, 8>(pd)));
       break;
     case OP_MUL_SUB_2SQR:
-      if constexpr (UB<C>::SPARSE)
+      if constexpr (UBS<C>::OK)
         store_u(po, u_mul_sub_2sqr(load_u<C, 2, 4>(pa), load_u<C, 4, 8>(pb), load_u<C, 2, 4>(pc)));
       break;
     case OP_MUL_TIGHT: store_u(po, u_mul(load_u<C, 1, 3>(pa), load_u<C, 1, 3>(pb))); break;

@@ -236,9 +236,14 @@ def test_merged_products_at_the_operand_bounds(fc):
     out = fc.run4(3, OP_MUL_ADD_MAX, a, b, c, d)
     for ra, rb, rc, rd, ro in zip(a, b, c, d, out):
         check_out(ro, inf, p, (value(ra, B) * value(rb, B) + value(rc, B) * value(rd, B)) * rinv)
-    # p384r1: curve 1
-    inf, p = fc.info(1), P[1]
-    rinv = pow(mont_factor(1, inf), -1, p)
+    # signed columns: p384r1 (sparse reduction) and bls12_381 (general reduction)
+    for curve in (1, 3):
+        _signed_merged_products(fc, rng, curve, n)
+
+
+def _signed_merged_products(fc, rng, curve, n):
+    inf, p = fc.info(curve), P[curve]
+    rinv = pow(mont_factor(curve, inf), -1, p)
     B = inf["B"]
     for op, ka, kb, kc, kd in ((OP_MUL_SUB, (1, 3), (3, 6), (1, 3), (1, 3)), (OP_MUL_SUB_MAX, (2, 4), (4, 8), (2, 4), (4, 8))):
         for order in range(3):
@@ -248,7 +253,7 @@ def test_merged_products_at_the_operand_bounds(fc):
                 rng.shuffle(c), rng.shuffle(d)
             elif order == 2:
                 rng.shuffle(a), rng.shuffle(b)
-            out = fc.run4(1, op, a, b, c, d)
+            out = fc.run4(curve, op, a, b, c, d)
             for ra, rb, rc, rd, ro in zip(a, b, c, d, out):
                 check_out(ro, inf, p, (value(ra, B) * value(rb, B) - value(rc, B) * value(rd, B)) * rinv)
     for order in range(3):
@@ -257,6 +262,6 @@ def test_merged_products_at_the_operand_bounds(fc):
             rng.shuffle(c)
         elif order == 2:
             rng.shuffle(a), rng.shuffle(b)
-        out = fc.run4(1, OP_MUL_SUB_2SQR, a, b, c, c)
+        out = fc.run4(curve, OP_MUL_SUB_2SQR, a, b, c, c)
         for ra, rb, rc, ro in zip(a, b, c, out):
             check_out(ro, inf, p, (value(ra, B) * value(rb, B) - 2 * value(rc, B) ** 2) * rinv)
