@@ -379,8 +379,8 @@ ECCX_DEV void u_mul_core_mers(uint32_t (&r)[C::N], const uint32_t (&a)[C::N], co
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     if constexpr (SQR) {
-      a2[i] = a[i] << 1;
-      bw[i] = a[i] << (S + 1);
+      a2[i] = a[i] << 1;  // also serves the wrapped cross terms: 2 (cross) * 2^S (wrap) = a2_i * a2_j for S = 1
+      bw[i] = (S == 1) ? 0u : a[i] << (S + 1);
     } else {
       a2[i] = 0;
       bw[i] = b[i] << S;
@@ -398,7 +398,10 @@ ECCX_DEV void u_mul_core_mers(uint32_t (&r)[C::N], const uint32_t (&a)[C::N], co
       if ((k & 1) == 0) qa.push(acc, a[k / 2], a[k / 2]);
       qa.flush(acc);
 #pragma unroll
-      for (int i = k + 1; 2 * i < k + N; ++i) qw.push(acc, a[i], bw[k + N - i]);
+      for (int i = k + 1; 2 * i < k + N; ++i) {
+        if constexpr (S == 1) qw.push(acc, a2[i], a2[k + N - i]);
+        else qw.push(acc, a[i], bw[k + N - i]);
+      }
       if (((k + N) & 1) == 0) {
         if constexpr (S == 1) qw.push(acc, a[(k + N) / 2], a2[(k + N) / 2]);
         else qw.push(acc, a2[(k + N) / 2], a2[(k + N) / 2]);
