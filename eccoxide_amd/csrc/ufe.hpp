@@ -37,6 +37,17 @@
 //   reduce      one carry chain that also takes off q*p, q ~ value / p estimated from the top
 //               limbs (shifted copies of q for the Solinas primes, 32-bit unsigned for kinds 2
 //               and 3, signed 64-bit otherwise): returns exact tight digits of a value < 3p
+//   merged products (one Montgomery reduction for two products; where a formula adds or subtracts
+//   two products -- the Y3 of the point formulas -- the second product's reduction, its column
+//   extractions and the carry chain of the difference go away):
+//     mul_add        a*b + c*d, general Montgomery (BLS12-381), unsigned columns; K1K2 + K3K4 <= KKMAX;
+//                    a subtraction is written (4p - c)*d
+//     mul_sub        a*b - c*d + p and
+//     mul_sub_2sqr   a*b - 2*c^2 + p on SIGNED columns (P-384, whose sparse reduction is signed anyway;
+//                    BLS12-381): the subtracted product goes in with v_mad_i64_i32 against negated
+//                    limbs, each side of a column within 63 bits (K1K2 <= UBS::KKS per product), p
+//                    added above R so that the result is in (0, 3p).  P-256 (9 x 29 bits) and P-521
+//                    have no room for either form.
 #pragma once
 #include "fe.hpp"
 

@@ -157,6 +157,8 @@ int eccx_scalar_bytes(int curve);
 /* Create / destroy a context on HIP device `device`. */
 int eccx_init(int device, eccx_ctx** out_ctx);
 void eccx_shutdown(eccx_ctx* ctx);
+/* the message of the last failing call on ctx; the pointer is a per-thread copy, valid until the
+ * calling thread's next eccx_last_error */
 const char* eccx_last_error(const eccx_ctx* ctx);
 const char* eccx_strerror(int code);
 
