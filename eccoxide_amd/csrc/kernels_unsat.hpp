@@ -1397,26 +1397,16 @@ __global__ void __launch_bounds__(WG) k_batch_to_affine_unsat(size_t n, const ui
     // fed a point that is not on the curve (rejected under ECCX_VALIDATE_POINTS, or garbage
     // without it) can arrive with Z = p or 2p -- e.g. an Edwards "point" with x = +-y doubles to
     // Z = 0 -- and must not zero the shared inverse of the units normalised beside it
-    // Straight-line on purpose: rows are read at a clamped index and the test is branch-free, so that
-    // the loads of all UN units can be in flight together -- with a branch per unit every load was
-    // followed by its own wait, UN + UN memory latencies in sequence in a kernel that runs one
-    // wavefront per SIMD and has nothing to hide them behind.
-    auto z_present = [&](const T& z) {
-      const auto r = u_reduce(z);
-      uint32_t d0 = 0, d1 = 0, d2 = 0;
-#pragma unroll
-      for (int k = 0; k < CU::N; ++k) { d0 |= r.v[k]; d1 |= r.v[k] ^ CU::P[k]; d2 |= r.v[k] ^ CU::P2[k]; }
-      return !(d0 == 0 || d1 == 0 || d2 == 0);
-    };
+    auto z_present = [&](const T& z) { return !u_is_zero_mod_p(u_reduce(z)); };
     T pre[UN];  // prefix products of the (substituted) Z values
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const size_t i = tile + (size_t)u * WG + threadIdx.x;
-      const size_t ii = i < n ? i : n - 1;
-      T x, y, z;
-      u3_load<CU>(x, y, z, rows + ii * (size_t)W3);
-      const bool use = (i < n) && z_present(z);  // z_inverse_ct substitutes 1 (projective.rs:655-659)
-      u_select(z, use, z, one);
+      T x, y, z = one;
+      if (i < n) {
+        u3_load<CU>(x, y, z, rows + i * (size_t)W3);
+        if (!z_present(z)) z = one;  // z_inverse_ct substitutes 1 (projective.rs:655-659)
+      }
       if (u == 0) pre[0] = z;
       else pre[u] = u_fit<1, 3>(u_mul(pre[u - 1], z));
     }
@@ -1427,31 +1417,16 @@ __global__ void __launch_bounds__(WG) k_batch_to_affine_unsat(size_t n, const ui
       fe_inv_gcd<CS>(c, c);
       inv = u_as<1, 3>(u_to_mont<CU>(c));
     }
-    // back-substitution, software-pipelined by hand: the row (and flag) of unit u - 1 is requested before
-    // unit u's arithmetic starts, because the stores at the end of each unit sit behind branches
-    // (alignment cases) that the scheduler does not move loads across
-    auto row_of = [&](int u) {
-      const size_t i = tile + (size_t)u * WG + threadIdx.x;
-      return rows + (i < n ? i : n - 1) * (size_t)W3;
-    };
-    auto flag_of = [&](int u) {
-      const size_t i = tile + (size_t)u * WG + threadIdx.x;
-      return flags[i < n ? i : n - 1];
-    };
-    T nx, ny, nz;
-    u3_load<CU>(nx, ny, nz, row_of(UN - 1));
-    uint8_t nflag = flag_of(UN - 1);
 #pragma unroll
     for (int u = UN - 1; u >= 0; --u) {
       const size_t i = tile + (size_t)u * WG + threadIdx.x;
-      T x = nx, y = ny, z = nz;
-      const uint8_t flag_in = nflag;
-      if (u > 0) {
-        u3_load<CU>(nx, ny, nz, row_of(u - 1));
-        nflag = flag_of(u - 1);
+      T x = one, y = one, z = one;
+      bool present = false;
+      if (i < n) {
+        u3_load<CU>(x, y, z, rows + i * (size_t)W3);
+        present = z_present(z);
+        if (!present) z = one;
       }
-      const bool present = (i < n) && z_present(z);
-      u_select(z, present, z, one);
       T zi;
       if (u > 0) {
         zi = u_fit<1, 3>(u_mul(inv, pre[u - 1]));
@@ -1469,7 +1444,7 @@ __global__ void __launch_bounds__(WG) k_batch_to_affine_unsat(size_t n, const ui
         if constexpr (MODE == NORM_EDWARDS || MODE == NORM_HOMOGENEOUS) u_to_canonical<CU>(ay, u_mul(y, zi));
       }
       if (i < n) {
-        const bool rejected = flag_in == 2;
+        const bool rejected = flags[i] == 2;
         if constexpr (MODE == NORM_MONTGOMERY_U) {
           if (!present) fe_zero<CS>(ax);
           fe_store_le<CS>(out + i * (size_t)FB, ax);
