@@ -44,18 +44,23 @@ def _sat(muls, pairs_per_mul):
     return {"pair": muls * pairs_per_mul, "mad": 0}
 
 
-def _var_unsat(n, nz, sb, a0, inv, sat_pairs, mont=True, norm_u=8, glv_bits=0, merged_y3=False):
-    """v_mad_u64_u32 per unit of the default variable-base path (kernels_unsat.hpp, kernels_bls.hpp):
-    n limbs of 28/29 bits, one mad per limb product.  A product is n*n mads, a square n(n+1)/2, a
-    Montgomery reduction n*nz (nz = non-zero reduction digits per Montgomery factor: those of p + 1
-    for P-256, the 4 signed terms of p + 1 for P-384, all n for BLS12-381, none for the Mersenne
-    prime whose wrapped half shares the columns).
-    a = -3: doubling 4 products + 4 squares, addition 11 + 3 (Jacobian entries with cached Z^2, Z^3);
-    window table: even entries by doubling, odd ones by addition (8 doublings + 7 additions), Z^2 and
-    Z^3 per entry; ceil((8*sb + 1)/5) signed windows of 5 doublings + 1 addition.
-    a = 0 (BLS12-381): doubling 3 products + 4 squares with 6 reductions (Y3 merged on signed columns); co-Z table (1 doubling + 14 mixed additions, then 4 products +
-    1 square per entry), mixed additions of 8 products + 3 squares with 10 reductions (Y3 merged);
-    merged_y3 (P-384): Y3 = alpha t - 2 (2 gamma)^2 and r (v - x3) - s1 h^3 take one reduction each.
+def _var_unsat(n, nz, sb, a0, inv, sat_pairs, mont=True, norm_u=8, glv_bits=0, merged_y3=False, inv30=(0, 0, 0)):
+    """v_mad_u64_u32 / v_mad_i64_i32 per unit of the default variable-base path (kernels_coz.hpp in front
+    of kernels_unsat.hpp): n limbs of 28/29 bits, one mad per limb product.  A product is n*n mads, a
+    square n(n+1)/2, a Montgomery reduction n*nz (nz = non-zero reduction digits per Montgomery factor:
+    those of p + 1 for P-256, the 4 signed terms of p + 1 for P-384, all n for BLS12-381, none for the
+    Mersenne prime whose wrapped half shares the columns).
+    Window table of 16 affine entries: 2P from the affine P (2 products + 4 squares), 14 co-Z additions
+    (4 products + 2 squares; a = -3: one more product for the running denominator), one pass to the
+    common denominator (4 products + 1 square per entry) -- on the a = -3 curves behind one division-step
+    inversion per unit: inv30 = (30-bit limbs, non-zero limbs of p, batches of 30 steps), per batch
+    8 mads per limb for the two 2x2 matrix updates + 2 per non-zero limb of p, and 2 products + 1
+    square for the conversions and entry 16.
+    Ladder: ceil((bits + 1)/5) signed windows of 5 doublings + 1 mixed addition (8 products + 3 squares);
+    the top window's entry is loaded, not added.
+    a = -3: doubling 4 products + 4 squares; merged_y3 (P-384): Y3 takes one reduction for two products
+    in the doubling and in the addition.
+    a = 0 (BLS12-381): doubling 3 products + 4 squares with 6 reductions, additions with 10 (Y3 merged);
     glv_bits > 0: the endomorphism form, two half-length scalars, 2 additions per window and one more
     product per entry (beta x).
     (inv, sat_pairs and norm_u are kept for reference only)"""
@@ -66,25 +71,44 @@ def _var_unsat(n, nz, sb, a0, inv, sat_pairs, mont=True, norm_u=8, glv_bits=0, m
 
     conv = cost(5, 0) if mont else 0                     # 2 products into the working form, 3 out of it
     norm = cost(9, 1)                                    # normalisation kernel: 7 products + 1 square + 2 conversions out
+    bits = glv_bits if glv_bits else 8 * sb
+    nwin = (bits + 1 + 4) // 5
+    per_entry = cost(4, 1) + (cost(1, 0) if glv_bits else 0)
     if a0:
-        bits = glv_bits if glv_bits else 8 * sb
-        nwin = (bits + 1 + 4) // 5
-        dbl, madd = cost(3, 4, 6) + 0, cost(8, 3, 10)   # doubling: X*B, E*t, Y*Z + X^2, Y^2, E^2 and -2(2B)^2 as a square; 6 reductions
-        per_entry = cost(4, 1) + (cost(1, 0) if glv_bits else 0)
-        total = dbl + 14 * madd + 15 * per_entry + (cost(1, 0) if glv_bits else 0)   # (+ beta x of entry 16)
-        total += (nwin - 1) * 5 * dbl + (nwin * (2 if glv_bits else 1) - 1) * madd + cost(1, 0)   # the top window's first entry is loaded, not added
-        return {"mad": total + conv + norm, "pair": 0}
+        dbl, madd = cost(3, 4, 6), cost(8, 3, 10)        # doubling: X*B, E*t, Y*Z + X^2, Y^2, E^2 and -2(2B)^2 as a square; 6 reductions
+        build = cost(2, 4) + 14 * cost(4, 2) + 15 * per_entry + (cost(1, 0) if glv_bits else 0)   # (+ beta x of entry 16)
+        tail = cost(1, 0)                                # Z *= zeta
+    else:
+        dbl, madd = cost(4, 4), cost(8, 3)
+        if merged_y3:   # P-384: Y3 is one reduction for two products (signed columns)
+            dbl, madd = cost(4, 4, 7), cost(8, 3, 10)
+        n30, nz30, batches = inv30
+        inversion = batches * (8 * n30 + 2 * nz30) + (cost(2, 0) if mont else 0)
+        build = cost(2, 4) + 14 * cost(5, 2) + inversion + cost(3, 1) + 15 * per_entry
+        tail = 0
+    total = build + (nwin - 1) * 5 * dbl + (nwin * (2 if glv_bits else 1) - 1) * madd + tail
+    return {"mad": total + conv + norm, "pair": 0}
+
+
+def _var_generic(n, nz, sb, mont=True):
+    """The generic ladder alone (kernels_unsat.hpp), as the fused verification kernel runs it: Jacobian
+    table entries with cached Z^2, Z^3 -- even entries by doubling, odd ones by addition (8 doublings + 7
+    additions of 11 products + 3 squares, 1 product + 1 square per entry), then per window 5 doublings
+    + 1 addition."""
+    prod, sq, red = n * n, n * (n + 1) // 2, n * nz
+
+    def cost(p, s):
+        return p * prod + s * sq + (p + s) * red
+
     nwin = (8 * sb + 1 + 4) // 5
     dbl, add = cost(4, 4), cost(11, 3)
-    if merged_y3:   # P-384: Y3 is one reduction for two products (signed columns), -8 gamma^2 stays a square
-        dbl, add = cost(4, 4, 7), cost(11, 3, 13)
-    total = 8 * dbl + 7 * add + 15 * cost(1, 1) + (nwin - 1) * 5 * dbl + (nwin - 1) * add   # the top window's entry is loaded, not added
-    return {"mad": total + conv + norm, "pair": 0}
+    total = 8 * dbl + 7 * add + 15 * cost(1, 1) + (nwin - 1) * 5 * dbl + (nwin - 1) * add
+    return {"mad": total + (cost(5, 0) if mont else 0) + cost(9, 1), "pair": 0}
 
 
 WORKLOADS = {
     # name: (curve, op, per-GPU batch, algorithmic bytes per unit, multiplier instructions per unit)
-    "p256r1_var_2^20": ("p256r1", "var", 1 << 20, 160, _var_unsat(9, 4, 32, 0, 383, 8 * 8 + 8 * 3, norm_u=16)),
+    "p256r1_var_2^20": ("p256r1", "var", 1 << 20, 160, _var_unsat(9, 4, 32, 0, 383, 8 * 8 + 8 * 3, norm_u=16, inv30=(9, 7, 25))),
     # fixed base, default path: 16-bit windows, 16 additions of 7 products (Edwards, 81 + 9 mads each)
     # or of 8 products + 3 squares (P-256) on unsaturated limbs, then the saturated normalisation
     "ed25519_base_2^20": ("ed25519", "base", 1 << 20, 96,
@@ -106,10 +130,9 @@ WORKLOADS = {
                          {"mad": (51 * 20 + 4) * 54 + (51 * 16 + 52 * 7 + 4 + 14 * 8 + 16 + 1 + 8) * 90, "pair": 0}),
     # verify shape u1*G + u2*Q: the variable-base ladder + 16 mixed additions (8 products + 3 squares)
     "p256r1_verify_2^20": ("p256r1", "dsm", 1 << 20, 192,
-                           {"mad": _var_unsat(9, 4, 32, 0, 383, 88, norm_u=16)["mad"] + 16 * (8 * 117 + 3 * 81),
-                            "pair": _var_unsat(9, 4, 32, 0, 383, 88, norm_u=16)["pair"]}),
-    "p384r1_var_2^19": ("p384r1", "var", 1 << 19, 240, _var_unsat(14, 4, 48, 0, 575, 12 * 12 + 12 * 10, merged_y3=True)),
-    "p521r1_var_2^19": ("p521r1", "var", 1 << 19, 330, _var_unsat(18, 0, 66, 0, 780, 17 * 17, mont=False)),
+                           {"mad": _var_generic(9, 4, 32)["mad"] + 16 * (8 * 117 + 3 * 81), "pair": 0}),
+    "p384r1_var_2^19": ("p384r1", "var", 1 << 19, 240, _var_unsat(14, 4, 48, 0, 575, 12 * 12 + 12 * 10, merged_y3=True, inv30=(13, 12, 37))),
+    "p521r1_var_2^19": ("p521r1", "var", 1 << 19, 330, _var_unsat(18, 0, 66, 0, 780, 17 * 17, mont=False, inv30=(18, 18, 51))),
     "bls12_381_g1_var_2^20": ("bls12_381_g1", "var", 1 << 20, 224, _var_unsat(14, 14, 32, 1, 570, 2 * 12 * 12)),
 }
 # multiplier instructions of the non-default variants that have a count of their own
@@ -122,7 +145,10 @@ VARIANT_MULT = {("bls12_381_g1_var_2^20", "glv"): _var_unsat(14, 14, 32, 1, 570,
 PROFILE_ROUND = "r02"
 # kernels of one step per workload op: substrings of the kernel names in the summary
 STEP_KERNELS = {
-    ("var", "default"): ["k_scalarmul_var_unsat<eccx::{U}, false>", "k_batch_to_affine_unsat<eccx::{U}, 1,"],
+    # variable base: the affine-table ladder, the generic ladder as its fix-up pass (reads the flags, redoes
+    # marked units: none in these workloads), the normalisation
+    ("var", "default"): ["k_scalarmul_coz_unsat<eccx::{U}, eccx::NoGlv, false>", "k_scalarmul_var_unsat<eccx::{U}, false>",
+                         "k_batch_to_affine_unsat<eccx::{U}, 1,"],
     ("var", "glv"): ["k_scalarmul_coz_unsat<eccx::{U}, eccx::BLS12_381_GLV, true>", "k_batch_to_affine_unsat<eccx::{U}, 1,"],
     ("var", "mirror"): ["k_scalarmul_var_mirror_unsat<eccx::{U}>", "k_batch_to_affine<eccx::{S}, 0,"],
     ("var", "ct"): ["k_scalarmul_var_mirror_unsat<eccx::{U}>", "k_batch_to_affine<eccx::{S}, 0,"],
@@ -136,8 +162,7 @@ ED_STEP_KERNELS = {
     ("base", "default"): ["k_ed_scalarmul_base_unsat<eccx::ED25519U>", "k_batch_to_affine_unsat<eccx::ED25519U, 2,"],
     ("base", "lds"): ["k_ed_scalarmul_base_lds6<eccx::ED25519U>", "k_batch_to_affine_unsat<eccx::ED25519U, 2,"],
 }
-# bls12_381_g1 variable base: the co-Z ladder, the generic ladder as its fix-up pass (reads the flags,
-# redoes marked units: none in this workload), the normalisation
+# bls12_381_g1 variable base: the same three kernels, the ladder instantiated with the curve's endomorphism constants
 BLS_STEP_KERNELS = {
     ("var", "default"): ["k_scalarmul_coz_unsat<eccx::BLS12_381U, eccx::BLS12_381_GLV, false>",
                          "k_scalarmul_var_unsat<eccx::BLS12_381U, false>", "k_batch_to_affine_unsat<eccx::BLS12_381U, 1,"],

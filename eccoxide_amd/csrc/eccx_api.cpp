@@ -134,7 +134,7 @@ int launch_var(eccx_ctx* ctx, const CurveOps* ops, size_t n, const uint8_t* d_sc
   if (n == 0) return ECCX_OK;
   const bool fast = !mirror && ops->var_fast && !d_proj && !(kopts & K_OUT_TABLE);
   if (fast && ops->var_coz && d_points && !(kopts & K_BASE_IS_GENERATOR)) {
-    // a = 0 curves: the ladder over a co-Z table (kernels_bls.hpp); glv: bases known to be in the
+    // Weierstrass curves: the ladder over an affine window table (kernels_coz.hpp); glv: bases known to be in the
     // prime-order subgroup.  Units with a base point of order <= 16 come back marked and are redone
     // by the generic ladder, which otherwise only reads the flags.
     const int g = glv ? 1 : 0;
@@ -555,7 +555,7 @@ int eccx_reserve(eccx_ctx* ctx, int curve, size_t max_n, uint32_t what) {
     const int grid = ops->var_fast_grid ? ops->var_fast_grid(ctx->cus, max_n) : grid_for(ctx, max_n);
     rc = ensure_scratch(ctx, ops->info.row5_words, grid);
     if (rc) return rc;
-    if (ops->var_coz) {  // a = 0 curves: the co-Z ladder's slab (both forms)
+    if (ops->var_coz) {  // the affine-table ladder's slab (both forms)
       rc = ensure_scratch(ctx, ops->coz_row_words, std::max(ops->var_coz_grid(ctx->cus, max_n, 0), ops->var_coz_grid(ctx->cus, max_n, 1)));
       if (rc) return rc;
     }

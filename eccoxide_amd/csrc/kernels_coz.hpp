@@ -1,9 +1,9 @@
 // Variable base over an AFFINE window table (all Weierstrass curves of the engine).
 //
-// The generic ladder (k_scalarmul_var_unsat) adds Jacobian table entries: 11 products + 5 squares
+// The generic ladder (k_scalarmul_var_unsat) adds Jacobian table entries: 11 products + 3 squares
 // per addition (Z^2, Z^3 of the entry cached).  Here the 16 entries d P are brought to a common
-// denominator first, so that every ladder addition is a MIXED addition (7 products + 4 squares, one
-// reduction merged):
+// denominator first, so that every ladder addition is a MIXED addition (8 products + 3 squares) and the
+// table itself is built with co-Z additions (4 products + 2 squares):
 //   a = 0 (BLS12-381 G1)   the ladder runs on the isomorphic curve E': y^2 = x^3 + b zeta^6 on which
 //                          the rescaled entries are affine; Z *= zeta at the end.  No inversion.
 //   a = -3 (P-256/384/521) the doubling uses a, so the ladder stays on the curve: the common
@@ -105,10 +105,11 @@ ECCX_DEV void glv_split(uint32_t (&k1)[5], uint32_t (&k2)[5], const uint8_t* __r
 
 // ---- variable base over an affine window table ----------------------------------------------------
 // The table is built with co-Z additions (uzaddu below): T_{d+1} = P + T_d with both operands over the same
-// denominator costs 5 products + 2 squares, leaves P over the new denominator Z_{d+1} = Z_d (X_P - X_T) for
-// the next step, and the ratio Z_{d+1} / Z_d falls out for free.
-//   table build   1 doubling (+ P brought over the denominator of 2P: 3 products + 1 square) + 14 co-Z
-//                 additions; rows (X_d, Y_d, ratio), each over the denominator of its own step
+// denominator costs 4 products + 2 squares (+ 1 product where the denominator itself is tracked), leaves P
+// over the new denominator Z_{d+1} = Z_d (X_P - X_T) for the next step, and the ratio Z_{d+1} / Z_d falls
+// out for free.
+//   table build   2P from the affine P (2 products + 4 squares; 4 x y^2 and 8 y^4 ARE P over the denominator
+//                 2 y of 2P) + 14 co-Z additions; rows (X_d, Y_d, ratio), each over the denominator of its step
 //   common Z      backward pass, per entry l *= ratio, l^2, l^3, X l^2, Y l^3 (4 products + 1 square);
 //                 l starts at 1 (a = 0: entries affine on E', zeta = Z_16 kept for the end) or at
 //                 1 / Z_16 (a = -3: entries affine on the curve itself)
@@ -174,7 +175,8 @@ ECCX_DEV void ujac_madd_signed(UJac<CU>& r, bool& h_zero, bool& r_zero, const UJ
 
 // Co-Z addition with update (Goundar-Joye-Miyaji ZADDU): p = (x1, y1) and t = (x2, y2) over the SAME
 // denominator Z.  t <- p + t and p <- p, both over the new denominator Z d with d = x1 - x2 (exported:
-// the ratio of the denominators).  5 products + 2 squares, none of them involving Z.
+// the ratio of the denominators).  4 products + 2 squares; Z itself is not touched (the caller multiplies
+// it by d where it needs the denominator).
 template <class CU>
 ECCX_DEV void uzaddu(U<CU, 1, 3>& x1, U<CU, 1, 3>& y1, U<CU, 1, 3>& x2, U<CU, 1, 3>& y2, U<CU, 1, 3>& d_out, bool& d_zero) {
   const auto d = u_reduce(u_sub(x1, x2));

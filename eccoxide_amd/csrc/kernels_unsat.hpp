@@ -300,7 +300,7 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_var_uns
     bool active = gid < n;
     const size_t idx = active ? gid : n - 1;
     if (opts & OPT_ONLY_MARKED) {
-      // fix-up pass behind the co-Z ladder (kernels_bls.hpp): only the units it marked are redone
+      // fix-up pass behind the affine-table ladder (kernels_coz.hpp): only the units it marked are redone
       active = active && flags[idx] == 0xFE;
       if (__builtin_amdgcn_ballot_w64(active) == 0) continue;
     }

@@ -80,8 +80,8 @@ struct CurveOps {
   hipError_t (*point_add_u)(int grid, hipStream_t s, size_t n, const uint8_t* a, const uint8_t* a_inf, const uint8_t* b,
                             const uint8_t* b_inf, uint32_t* rows, uint8_t* flags, uint32_t opts);
   hipError_t (*to_affine_add_u)(int grid, hipStream_t s, size_t n, const uint32_t* rows, uint8_t* out, uint8_t* flags);
-  // a = 0 curves (bls12_381_g1; null / 0 elsewhere), kernels_bls.hpp: the variable-base ladder over a
-  // co-Z window table (mixed additions); glv != 0 selects the endomorphism form for bases known to be
+  // Weierstrass curves (null / 0 for edwards25519), kernels_coz.hpp: the variable-base ladder over an
+  // affine window table (mixed additions); glv != 0 selects the endomorphism form (bls12_381_g1) for bases known to be
   // in the prime-order subgroup.  Rows for to_affine_var; scratch rows of coz_row_words.  Units whose
   // base point has order <= 16 come back marked (flag 0xFE) and are redone by var_fast launched with
   // the only-marked option.  subgroup_check: the membership test applied in place to decompressed

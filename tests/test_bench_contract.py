@@ -48,11 +48,17 @@ def test_unprofiled_workload_reports_null_traffic():
 
 def test_multiplier_model():
     m = bench.WORKLOADS["p256r1_var_2^20"][4]["mad"]
-    # 9-limb P-256: product 81 + 36, square 45 + 36; doubling 4 + 4, addition 11 + 3
-    dbl, add = 4 * 117 + 4 * 81, 11 * 117 + 3 * 81
-    assert dbl == 792 and add == 1530
-    ladder = (8 + 51 * 5) * dbl + (7 + 51) * add + 15 * (117 + 81)
-    assert 0 < m - ladder < 3000                       # the rest: conversions and the normalisation's products
+    # 9-limb P-256: product 81 + 36, square 45 + 36; doubling 4 + 4, mixed addition 8 + 3, co-Z addition 5 + 2
+    # (the denominator tracked), rescaling 4 + 1 per entry, 2P from the affine P 2 + 4
+    dbl, madd, zaddu, scale = 4 * 117 + 4 * 81, 8 * 117 + 3 * 81, 5 * 117 + 2 * 81, 4 * 117 + 81
+    assert dbl == 792 and madd == 1179 and zaddu == 747
+    ladder = 51 * 5 * dbl + 51 * madd + (2 * 117 + 4 * 81) + 14 * zaddu + 15 * scale
+    inversion = 25 * (8 * 9 + 2 * 7)
+    assert 0 < m - ladder - inversion < 3500            # the rest: conversions, entry 16 and the normalisation's products
+    # the generic ladder (table of Jacobian entries), as the fused verification kernel still runs it
+    g = bench._var_generic(9, 4, 32)["mad"]
+    assert 0 < g - ((8 + 51 * 5) * dbl + (7 + 51) * (11 * 117 + 3 * 81) + 15 * (117 + 81)) < 3000
+    assert m < g
     glv = bench.VARIANT_MULT[("bls12_381_g1_var_2^20", "glv")]["mad"]
     assert glv < 0.7 * bench.WORKLOADS["bls12_381_g1_var_2^20"][4]["mad"]
 

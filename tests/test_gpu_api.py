@@ -438,3 +438,36 @@ def test_bls_low_order_bases_among_ordinary_ones(engine, oracle):
     for i in range(n):
         if i not in where:
             assert got_g[0][i * 96:(i + 1) * 96] == want[0][i * 96:(i + 1) * 96] and got_g[1][i] == want[1][i]
+
+
+@pytest.mark.parametrize("curve", ["p256r1", "p384r1", "p521r1"])
+def test_garbage_bases_do_not_disturb_their_neighbours(engine, oracle, curve):
+    """The prime-order curves have no point of order <= 16, so the affine-table ladder's fix-up pass
+    only ever sees bytes that are not a curve point (callers that skip ECCX_VALIDATE_POINTS): y = 0 makes
+    the very first doubling degenerate, x = y = 0 every step.  Such units get SOME result (flag 0 or 1,
+    never the internal marker), every other unit of the same wavefronts the oracle's; with validation
+    they are rejected and nothing else changes."""
+    fb, sb = _SIZES[curve]
+    n = 700
+    pts = bytearray(_bases(oracle, curve, n, seed=1201))
+    bad = list(range(3, n, 61))
+    for j, i in enumerate(bad):
+        if j % 2 == 0:
+            pts[i * 2 * fb + fb:(i + 1) * 2 * fb] = bytes(fb)           # (x, 0)
+        else:
+            pts[i * 2 * fb:(i + 1) * 2 * fb] = bytes(2 * fb)            # (0, 0)
+    pts = bytes(pts)
+    ks = W.random_scalars(curve, n, seed=1202).tobytes()
+    good_pts = bytearray(pts)
+    for i in bad:                                                       # the oracle gets a valid stand-in there
+        good_pts[i * 2 * fb:(i + 1) * 2 * fb] = pts[0:2 * fb]
+    want = oracle.var(curve, ks, bytes(good_pts), threads=16)
+    got = engine.scalarmul_var(curve, ks, pts)
+    chk = engine.scalarmul_var(curve, ks, pts, validate=True)
+    for i in range(n):
+        if i in bad:
+            assert got[1][i] in (0, 1)
+            assert chk[1][i] == 2 and chk[0][i * 2 * fb:(i + 1) * 2 * fb] == bytes(2 * fb)
+        else:
+            for r in (got, chk):
+                assert r[0][i * 2 * fb:(i + 1) * 2 * fb] == want[0][i * 2 * fb:(i + 1) * 2 * fb] and r[1][i] == want[1][i]
