@@ -8,8 +8,11 @@
 // of (30 steps on one word + two 2x2-matrix updates of 9-limb numbers) for a 256-bit field:
 // about a sixth of a Fermat chain of ~260 field multiplications.
 //
-// Fixed iteration count (the delta = 1 division step, floor((49 bits + 57) / 17) steps rounded up
-// to batches of 30: valid for every odd modulus), no data-dependent control flow.
+// Fixed iteration count, no data-dependent control flow: the delta = 1 division step with
+// floor((49 bits + 57) / 17) steps rounded up to batches of 30 (valid for every odd modulus), or -- for
+// the moduli of at most 256 bits, C::INV30_HD -- the step started at delta = 1/2 ("hddivsteps"), for which
+// 590 steps are proven to suffice below 2^256 (github.com/sipa/safegcd-bounds; libsecp256k1's modinv32
+// runs the same 20 batches of 30): 20 batches instead of 25.
 // Numbers are little-endian 30-bit limbs, all but the top one in [0, 2^30), the top one signed.
 #pragma once
 #include "fe.hpp"
@@ -25,8 +28,9 @@ struct Trans30 {
   int32_t u, v, q, r;
 };
 
-// 30 division steps on the low words of f and g; eta = -delta.  Afterwards
-// (f', g') = 2^-30 * (u v; q r) * (f, g).
+// 30 division steps on the low words of f and g; eta = -delta (HD: eta = -(delta + 1/2), delta starting
+// at 1/2).  Afterwards (f', g') = 2^-30 * (u v; q r) * (f, g).
+template <bool HD>
 ECCX_DEV int32_t divsteps_30(int32_t eta, uint32_t f0, uint32_t g0, Trans30& t) {
   uint32_t u = 1, v = 0, q = 0, r = 1;
   uint32_t f = f0, g = g0;
@@ -39,7 +43,8 @@ ECCX_DEV int32_t divsteps_30(int32_t eta, uint32_t f0, uint32_t g0, Trans30& t) 
     q += y & c2;
     r += z & c2;
     c1 &= c2;                                            // swap case: delta > 0 and g odd
-    eta = (int32_t)(((uint32_t)eta ^ c1) - (c1 + 1u));   // delta -> 1 - delta or 1 + delta
+    if (HD) eta = (int32_t)(((uint32_t)eta ^ c1) - 1u);  // delta -> 1 - delta or 1 + delta on delta + 1/2
+    else eta = (int32_t)(((uint32_t)eta ^ c1) - (c1 + 1u));   // delta -> 1 - delta or 1 + delta
     f += g & c1;
     u += q & c1;
     v += r & c1;
@@ -150,7 +155,7 @@ __device__ __noinline__ void fe_inv_gcd(Fe<C::L>& r, const Fe<C::L>& a) {
   int32_t eta = -1;
   for (int b = 0; b < C::INV30_BATCHES; ++b) {
     Trans30 t;
-    eta = divsteps_30(eta, (uint32_t)f.v[0], (uint32_t)g.v[0], t);
+    eta = divsteps_30<C::INV30_HD>(eta, (uint32_t)f.v[0], (uint32_t)g.v[0], t);
     update_de_30<C>(d, e, t);
     update_fg_30<C>(f, g, t);
   }

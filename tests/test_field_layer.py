@@ -187,6 +187,41 @@ def test_canonical_output_is_the_unique_residue(fc, curve):
         assert got == value(ra, inf["B"]) * rinv % p
 
 
+def _hd_divsteps_needed(p, a, limit):
+    """Division steps started at delta = 1/2 (zeta = -(delta + 1/2) = -1), in Python integers: the
+    number of steps until g = 0, or None if `limit` does not suffice."""
+    zeta, f, g = -1, p, a
+    for i in range(limit):
+        if g == 0:
+            assert abs(f) == 1 or a == 0
+            return i
+        if zeta < 0 and (g & 1):
+            zeta, f, g = -zeta - 2, g, (g - f) >> 1
+        else:
+            zeta, g = zeta - 1, (g + (g & 1) * f) >> 1
+    return i + 1 if g == 0 else None
+
+
+@pytest.mark.parametrize("curve", [0, 4], ids=lambda c: NAMES[c])
+def test_half_delta_division_steps_stay_inside_the_proven_bound(curve):
+    """inv_gcd.hpp runs 20 batches of 30 division steps for the 256-bit fields (INV30_HD): 590 are proven
+    to suffice for every odd modulus below 2^256 when delta starts at 1/2 (the bound libsecp256k1's
+    modinv32 relies on).  A model of the same step rule in Python integers, over edge values and random
+    ones: no input comes near the 600 steps the kernel runs."""
+    rng = random.Random(4400 + curve)
+    p = P[curve]
+    assert p.bit_length() <= 256
+    vals = [1, 2, 3, p - 1, p - 2, (p - 1) // 2, (p + 1) // 2, 1 << 255 if p >> 255 else 1 << 254, (1 << 254) - 1]
+    vals += [1 << k for k in range(1, 255, 7)] + [p - (1 << k) for k in range(0, 254, 11)]
+    vals += [rng.randrange(1, p) for _ in range(4000)]
+    worst = 0
+    for v in vals:
+        need = _hd_divsteps_needed(p, v % p, 600)
+        assert need is not None and need <= 590, hex(v)
+        worst = max(worst, need)
+    assert worst > 300          # the model really iterates
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("curve", [0, 1, 2, 3, 4], ids=lambda c: NAMES[c])
 def test_division_step_inversion(fc, curve):

@@ -97,13 +97,18 @@ def emit_field(out, p, L, mersenne=0, pm19=0):
     out.append("  static constexpr int PBITS = %d;" % p.bit_length())
     # constants of the division-step inversion (inv_gcd.hpp): the modulus in 30-bit limbs,
     # p^-1 mod 2^30, and the number of 30-step batches that the Bernstein-Yang bound
-    # floor((49 bits + 57) / 17) divsteps (delta = 1 variant, any odd modulus) rounds up to
+    # floor((49 bits + 57) / 17) divsteps (delta = 1 variant, any odd modulus) rounds up to (but see INV30_HD)
     nl = (p.bit_length() + 1 + 29) // 30 + (1 if (p.bit_length() + 1) % 30 == 0 else 0)
     nl = max(nl, (p.bit_length() + 2 + 29) // 30)  # room for values in (-2p, p) with a sign bit
     out.append("  static constexpr int INV30_N = %d;" % nl)
     out.append("  static constexpr int32_t P30[%d] = {%s};" % (nl, ", ".join("0x%08x" % ((p >> (30 * i)) & 0x3FFFFFFF) for i in range(nl))))
     out.append("  static constexpr uint32_t P30_INV = 0x%08xu;  // p^-1 mod 2^30" % pow(p, -1, 1 << 30))
-    out.append("  static constexpr int INV30_BATCHES = %d;" % (((49 * p.bit_length() + 57) // 17 + 29) // 30))
+    # moduli of at most 256 bits: the division step started at delta = 1/2, for which 590 steps are PROVEN
+    # to suffice for every odd modulus below 2^256 (convex-hull bound of github.com/sipa/safegcd-bounds, the
+    # figure libsecp256k1's modinv32 relies on: 20 batches of 30) -- against 724 / 741 with delta = 1
+    hd = p.bit_length() <= 256
+    out.append("  static constexpr bool INV30_HD = %s;  // division steps start at delta = 1/2" % ("true" if hd else "false"))
+    out.append("  static constexpr int INV30_BATCHES = %d;" % (20 if hd else ((49 * p.bit_length() + 57) // 17 + 29) // 30))
     return R
 
 
