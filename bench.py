@@ -108,7 +108,7 @@ def _var_generic(n, nz, sb, mont=True):
 
 WORKLOADS = {
     # name: (curve, op, per-GPU batch, algorithmic bytes per unit, multiplier instructions per unit)
-    "p256r1_var_2^20": ("p256r1", "var", 1 << 20, 160, _var_unsat(9, 4, 32, 0, 383, 8 * 8 + 8 * 3, norm_u=16, inv30=(9, 7, 25))),
+    "p256r1_var_2^20": ("p256r1", "var", 1 << 20, 160, _var_unsat(9, 4, 32, 0, 383, 8 * 8 + 8 * 3, norm_u=16, inv30=(9, 7, 20))),
     # fixed base, default path: 16-bit windows, 16 additions of 7 products (Edwards, 81 + 9 mads each)
     # or of 8 products + 3 squares (P-256) on unsaturated limbs, then the saturated normalisation
     "ed25519_base_2^20": ("ed25519", "base", 1 << 20, 96,
@@ -130,7 +130,7 @@ WORKLOADS = {
                          {"mad": (51 * 20 + 4) * 54 + (51 * 16 + 52 * 7 + 4 + 14 * 8 + 16 + 1 + 8) * 90, "pair": 0}),
     # verify shape u1*G + u2*Q: the variable-base ladder + 16 mixed additions (8 products + 3 squares)
     "p256r1_verify_2^20": ("p256r1", "dsm", 1 << 20, 192,
-                           {"mad": _var_generic(9, 4, 32)["mad"] + 16 * (8 * 117 + 3 * 81), "pair": 0}),
+                           {"mad": _var_unsat(9, 4, 32, 0, 383, 88, norm_u=16, inv30=(9, 7, 20))["mad"] + 16 * (8 * 117 + 3 * 81), "pair": 0}),
     "p384r1_var_2^19": ("p384r1", "var", 1 << 19, 240, _var_unsat(14, 4, 48, 0, 575, 12 * 12 + 12 * 10, merged_y3=True, inv30=(13, 12, 37))),
     "p521r1_var_2^19": ("p521r1", "var", 1 << 19, 330, _var_unsat(18, 0, 66, 0, 780, 17 * 17, mont=False, inv30=(18, 18, 51))),
     "bls12_381_g1_var_2^20": ("bls12_381_g1", "var", 1 << 20, 224, _var_unsat(14, 14, 32, 1, 570, 2 * 12 * 12)),
@@ -147,12 +147,13 @@ PROFILE_ROUND = "r02"
 STEP_KERNELS = {
     # variable base: the affine-table ladder, the generic ladder as its fix-up pass (reads the flags, redoes
     # marked units: none in these workloads), the normalisation
-    ("var", "default"): ["k_scalarmul_coz_unsat<eccx::{U}, eccx::NoGlv, false>", "k_scalarmul_var_unsat<eccx::{U}, false>",
+    ("var", "default"): ["k_scalarmul_coz_unsat<eccx::{U}, eccx::NoGlv, false, false>", "k_scalarmul_var_unsat<eccx::{U}, false>",
                          "k_batch_to_affine_unsat<eccx::{U}, 1,"],
-    ("var", "glv"): ["k_scalarmul_coz_unsat<eccx::{U}, eccx::BLS12_381_GLV, true>", "k_batch_to_affine_unsat<eccx::{U}, 1,"],
+    ("var", "glv"): ["k_scalarmul_coz_unsat<eccx::{U}, eccx::BLS12_381_GLV, true, false>", "k_batch_to_affine_unsat<eccx::{U}, 1,"],
     ("var", "mirror"): ["k_scalarmul_var_mirror_unsat<eccx::{U}>", "k_batch_to_affine<eccx::{S}, 0,"],
     ("var", "ct"): ["k_scalarmul_var_mirror_unsat<eccx::{U}>", "k_batch_to_affine<eccx::{S}, 0,"],
-    ("dsm", "default"): ["k_scalarmul_var_unsat<eccx::{U}, true>", "k_batch_to_affine_unsat<eccx::{U}, 1,"],
+    ("dsm", "default"): ["k_scalarmul_coz_unsat<eccx::{U}, eccx::NoGlv, false, true>", "k_scalarmul_var_unsat<eccx::{U}, true>",
+                         "k_batch_to_affine_unsat<eccx::{U}, 1,"],
     ("base", "default"): ["k_scalarmul_base_unsat<eccx::{U}>", "k_batch_to_affine_unsat<eccx::{U}, 1,"],
     ("x25519", "default"): ["k_x25519_ladder_unsat<eccx::ED25519U>", "k_batch_to_affine_unsat<eccx::ED25519U, 3,"],
 }
@@ -164,9 +165,9 @@ ED_STEP_KERNELS = {
 }
 # bls12_381_g1 variable base: the same three kernels, the ladder instantiated with the curve's endomorphism constants
 BLS_STEP_KERNELS = {
-    ("var", "default"): ["k_scalarmul_coz_unsat<eccx::BLS12_381U, eccx::BLS12_381_GLV, false>",
+    ("var", "default"): ["k_scalarmul_coz_unsat<eccx::BLS12_381U, eccx::BLS12_381_GLV, false, false>",
                          "k_scalarmul_var_unsat<eccx::BLS12_381U, false>", "k_batch_to_affine_unsat<eccx::BLS12_381U, 1,"],
-    ("var", "glv"): ["k_scalarmul_coz_unsat<eccx::BLS12_381U, eccx::BLS12_381_GLV, true>",
+    ("var", "glv"): ["k_scalarmul_coz_unsat<eccx::BLS12_381U, eccx::BLS12_381_GLV, true, false>",
                      "k_scalarmul_var_unsat<eccx::BLS12_381U, false>", "k_batch_to_affine_unsat<eccx::BLS12_381U, 1,"],
 }
 CURVE_STRUCTS = {"p256r1": ("P256", "P256U"), "p384r1": ("P384", "P384U"), "p521r1": ("P521", "P521U"),

@@ -825,9 +825,19 @@ int eccx_double_scalarmul_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_
   rc = ensure_rows(ctx, ops, n);
   if (rc) return rc;
   const uint32_t kopts = kopts_of(opts) | ((opts & ECCX_SUBTRACT) ? K_NEGATE_B : 0u);
+  if (ops->var_coz_fused) {
+    // Weierstrass curves: the ladder over an affine window table (kernels_coz.hpp), then the generic fused
+    // kernel for the units it marked (none unless a base has order <= 16 or is not a curve point)
+    const int gridc = ops->var_coz_fused_grid(ctx->cus, n);
+    rc = ensure_scratch(ctx, ops->coz_row_words, gridc);
+    if (rc) return rc;
+    HIP_TRY(ctx, ops->var_coz_fused(gridc, s, n, static_cast<const uint8_t*>(d_u2), static_cast<const uint8_t*>(d_q), ctx->jac,
+                                    static_cast<uint8_t*>(d_flags), ctx->scratch, kopts, static_cast<const uint8_t*>(d_u1),
+                                    ctx->comb_u[curve]));
+  }
   HIP_TRY(ctx, ops->var_fused(grid, s, n, static_cast<const uint8_t*>(d_u2), static_cast<const uint8_t*>(d_q), ctx->jac,
-                              static_cast<uint8_t*>(d_flags), ctx->scratch, kopts, static_cast<const uint8_t*>(d_u1),
-                              ctx->comb_u[curve]));
+                              static_cast<uint8_t*>(d_flags), ctx->scratch, kopts | (ops->var_coz_fused ? K_ONLY_MARKED : 0u),
+                              static_cast<const uint8_t*>(d_u1), ctx->comb_u[curve]));
   HIP_TRY(ctx, ops->to_affine_var(norm_grid(ctx, n), s, n, ctx->jac, static_cast<uint8_t*>(d_out),
                                   static_cast<uint8_t*>(d_flags)));
   return ECCX_OK;

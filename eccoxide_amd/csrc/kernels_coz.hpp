@@ -198,12 +198,17 @@ ECCX_DEV void uzaddu(U<CU, 1, 3>& x1, U<CU, 1, 3>& y1, U<CU, 1, 3>& x2, U<CU, 1,
 
 // scratch: [workgroup][row 0..16][thread][urowc_words]; row 0: split scalar (words 0..15, GLV) and
 // zeta (words 16..16+N); rows 1..16: the table
-template <class CU, class G, bool GLV>
+// FUSED: the verify shape u1*G + u2*Q (u1*G - u2*Q with OPT_NEGATE_B; src/protocol/ecdsa.rs:215) in one pass, as in
+// k_scalarmul_var_unsat<CU, true>: the ladder computes u2*(+-Q), the 16-bit comb of u1*G is accumulated onto it.
+template <class CU, class G, bool GLV, bool FUSED = false>
 __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_coz_unsat(size_t n, const uint8_t* __restrict__ scalars,
                                                                                  const uint8_t* __restrict__ points,
                                                                                  uint32_t* __restrict__ rows_out,
                                                                                  uint8_t* __restrict__ flags,
-                                                                                 uint32_t* __restrict__ scratch, uint32_t opts) {
+                                                                                 uint32_t* __restrict__ scratch, uint32_t opts,
+                                                                                 const uint8_t* __restrict__ base_scalars = nullptr,
+                                                                                 const uint32_t* __restrict__ utable = nullptr) {
+  static_assert(!(GLV && FUSED), "the verify shape takes any curve point");
   using CS = typename CU::Sat;
   constexpr bool ISO = CS::A0 == 1;  // a = 0: isomorphic curve, no inversion
   constexpr int L = CS::L;
@@ -250,6 +255,9 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_coz_uns
       }
       q.x = u_as<1, 3>(u_to_mont<CU>(rx));
       q.y = u_as<1, 3>(u_to_mont<CU>(ry));
+    }
+    if constexpr (FUSED) {
+      if (opts & OPT_NEGATE_B) q.y = u_reduce(u_neg(q.y));  // u1*G - u2*Q
     }
     q.z = u_as<UJac<CU>::ZK, UJac<CU>::ZV>(one);
     u3_store<CU>(row(1), q.x, q.y, one);
@@ -448,6 +456,7 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_coz_uns
       for (int i = 0; i < N; ++i) zeta.v[i] = zsrc[i];
       q.z = u_fit<UJac<CU>::ZK, UJac<CU>::ZV>(u_mul(q.z, zeta));
     }
+    if constexpr (FUSED) ucomb_accumulate<CU, false>(q, base_scalars + idx * (size_t)SB, utable);
     if (active) {
       u3_store<CU>(rows_out + idx * (size_t)urow3_words<CU>(), q.x, q.y, u_fit<1, 3>(q.z));
       flags[idx] = rejected ? 2 : (degenerate ? FLAG_REDO : 0);

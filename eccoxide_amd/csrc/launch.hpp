@@ -90,6 +90,10 @@ struct CurveOps {
                         uint8_t* flags, uint32_t* scratch, uint32_t opts, int glv);
   int (*var_coz_grid)(int cus, size_t n, int glv);
   int coz_row_words;
+  // the verify shape over the same ladder (arguments as var_fused)
+  hipError_t (*var_coz_fused)(int grid, hipStream_t s, size_t n, const uint8_t* u2, const uint8_t* q, uint32_t* rows, uint8_t* flags,
+                              uint32_t* scratch, uint32_t opts, const uint8_t* u1, const uint32_t* utable);
+  int (*var_coz_fused_grid)(int cus, size_t n);
   hipError_t (*subgroup_check)(int grid, hipStream_t s, size_t n, uint8_t* xy, uint8_t* flags);
 };
 // units normalised per lane with one inversion: 16 where the prefix products fit the register

@@ -53,7 +53,7 @@ def test_multiplier_model():
     dbl, madd, zaddu, scale = 4 * 117 + 4 * 81, 8 * 117 + 3 * 81, 5 * 117 + 2 * 81, 4 * 117 + 81
     assert dbl == 792 and madd == 1179 and zaddu == 747
     ladder = 51 * 5 * dbl + 51 * madd + (2 * 117 + 4 * 81) + 14 * zaddu + 15 * scale
-    inversion = 25 * (8 * 9 + 2 * 7)
+    inversion = 20 * (8 * 9 + 2 * 7)                    # 20 batches of 30 division steps (delta = 1/2 variant)
     assert 0 < m - ladder - inversion < 3500            # the rest: conversions, entry 16 and the normalisation's products
     # the generic ladder (table of Jacobian entries), as the fused verification kernel still runs it
     g = bench._var_generic(9, 4, 32)["mad"]
