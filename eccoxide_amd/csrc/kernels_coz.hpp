@@ -207,8 +207,11 @@ ECCX_DEV void uzaddu(U<CU, 1, 3>& x1, U<CU, 1, 3>& y1, U<CU, 1, 3>& x2, U<CU, 1,
 #ifndef ECCX_COZ_OCC_U14
 #define ECCX_COZ_OCC_U14 3
 #endif
+#ifndef ECCX_COZ_OCC_U9
+#define ECCX_COZ_OCC_U9 4
+#endif
 template <class CU, bool GLV>
-constexpr int coz_occupancy() { return CU::N <= 9 ? 4 : (CU::N <= 14 ? (GLV ? ECCX_OCC_U14 : ECCX_COZ_OCC_U14) : ECCX_OCC_U18); }
+constexpr int coz_occupancy() { return CU::N <= 9 ? ECCX_COZ_OCC_U9 : (CU::N <= 14 ? (GLV ? ECCX_OCC_U14 : ECCX_COZ_OCC_U14) : ECCX_OCC_U18); }
 
 template <class CU, class G, bool GLV, bool FUSED = false>
 __global__ void __launch_bounds__(WG, (coz_occupancy<CU, GLV>())) k_scalarmul_coz_unsat(size_t n, const uint8_t* __restrict__ scalars,
