@@ -196,14 +196,11 @@ ECCX_DEV void uzaddu(U<CU, 1, 3>& x1, U<CU, 1, 3>& y1, U<CU, 1, 3>& x2, U<CU, 1,
   d_out = d;
 }
 
-// scratch: [workgroup][row 0..16][thread][urowc_words]; row 0: split scalar (words 0..15, GLV) and
-// zeta (words 16..16+N); rows 1..16: the table
-// FUSED: the verify shape u1*G + u2*Q (u1*G - u2*Q with OPT_NEGATE_B; src/protocol/ecdsa.rs:215) in one pass, as in
-// k_scalarmul_var_unsat<CU, true>: the ladder computes u2*(+-Q), the 16-bit comb of u1*G is accumulated onto it.
-// waves per SIMD the kernel is compiled for: the mixed additions keep two coordinates of an entry live where
-// the generic ladder keeps five, so the 14-limb fields fit three waves (measured against two: P-384 19.92 ->
+// Waves per SIMD the kernel is compiled for: the mixed additions keep two coordinates of an entry live where
+// the generic ladder keeps five, so the 14-limb fields fit three waves (measured against two: P-384 19.49 ->
 // 18.67 ms, BLS12-381 34.55 -> 34.07 ms; the generic 14-limb ladder was 8 % SLOWER at three, and the GLV form,
-// whose rows carry a third column, loses 0.7 %: it stays at two)
+// whose rows carry a third column, loses 0.7 %: it stays at two).  9 limbs: three equal to four, five +5.5 %;
+// 18 limbs: three +16 %.
 #ifndef ECCX_COZ_OCC_U14
 #define ECCX_COZ_OCC_U14 3
 #endif
@@ -213,6 +210,10 @@ ECCX_DEV void uzaddu(U<CU, 1, 3>& x1, U<CU, 1, 3>& y1, U<CU, 1, 3>& x2, U<CU, 1,
 template <class CU, bool GLV>
 constexpr int coz_occupancy() { return CU::N <= 9 ? ECCX_COZ_OCC_U9 : (CU::N <= 14 ? (GLV ? ECCX_OCC_U14 : ECCX_COZ_OCC_U14) : ECCX_OCC_U18); }
 
+// scratch: [workgroup][row 0..16][thread][urowc_words]; row 0: split scalar (words 0..15, GLV) and
+// zeta (words 16..16+N); rows 1..16: the table.
+// FUSED: the verify shape u1*G + u2*Q (u1*G - u2*Q with OPT_NEGATE_B; src/protocol/ecdsa.rs:215) in one pass, as in
+// k_scalarmul_var_unsat<CU, true>: the ladder computes u2*(+-Q), the 16-bit comb of u1*G is accumulated onto it.
 template <class CU, class G, bool GLV, bool FUSED = false>
 __global__ void __launch_bounds__(WG, (coz_occupancy<CU, GLV>())) k_scalarmul_coz_unsat(size_t n, const uint8_t* __restrict__ scalars,
                                                                                  const uint8_t* __restrict__ points,
