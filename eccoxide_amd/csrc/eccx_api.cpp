@@ -556,7 +556,9 @@ int eccx_reserve(eccx_ctx* ctx, int curve, size_t max_n, uint32_t what) {
     rc = ensure_scratch(ctx, ops->info.row5_words, grid);
     if (rc) return rc;
     if (ops->var_coz) {  // the affine-table ladder's slab (both forms)
-      rc = ensure_scratch(ctx, ops->coz_row_words, std::max(ops->var_coz_grid(ctx->cus, max_n, 0), ops->var_coz_grid(ctx->cus, max_n, 1)));
+      int g = std::max(ops->var_coz_grid(ctx->cus, max_n, 0), ops->var_coz_grid(ctx->cus, max_n, 1));
+      if (ops->var_coz_fused_grid) g = std::max(g, ops->var_coz_fused_grid(ctx->cus, max_n));  // the verify shape
+      rc = ensure_scratch(ctx, ops->coz_row_words, g);
       if (rc) return rc;
     }
   }
