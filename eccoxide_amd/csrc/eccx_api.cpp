@@ -608,7 +608,9 @@ int eccx_scalarmul_base_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_sc
   int rc = ensure_comb(ctx, curve, ops, s);
   if (rc) return rc;
   size_t need = (n + eccx::LAUNCH_WG - 1) / eccx::LAUNCH_WG;
-  int grid = (int)std::max<size_t>(1, std::min(need, (size_t)ctx->cus * 8));
+  // up to 16 workgroups per CU: at 2^20 units every lane then takes ONE unit and the hardware's dispatcher
+  // balances the tail (measured against 8 and 4 per CU: Ed25519 0.733 / 0.747 / 0.768 ms, P-256 1.110 / 1.126 / 1.142)
+  int grid = (int)std::max<size_t>(1, std::min(need, (size_t)ctx->cus * 16));
   // default: 16-bit windows over the engine's own wide table (the 4-bit comb of the reference's
   // layout stays reachable through ECCX_MIRROR_REFERENCE / ECCX_TABLE_IN_LDS / ECCX_TABLE_IN_L2)
   const uint32_t ct = (opts & ECCX_CT_SCAN) ? K_CT_SCAN : 0u;  // reference-layout 4-bit comb, every entry read
