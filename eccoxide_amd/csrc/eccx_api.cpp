@@ -52,6 +52,7 @@ struct eccx_ctx {
   uint32_t* comb[NCURVES] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   uint32_t* comb_u[NCURVES] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // unsaturated-field copies
   uint32_t* comb_lds[NCURVES] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // images for the LDS variant
+  uint32_t* comb_ct[NCURVES] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // signed-window tables of the secret-scalar path
   std::mutex comb_mu;
   uint32_t* scratch = nullptr;
   size_t scratch_words = 0;
@@ -77,6 +78,16 @@ namespace {
       return e_ == hipErrorOutOfMemory ? ECCX_ERR_NOMEM : ECCX_ERR_HIP;                        \
     }                                                                                          \
   } while (0)
+
+// argument errors leave a message too: eccx_last_error() must never hand out a stale HIP string for them
+int arg_err(eccx_ctx* ctx, const char* what) {
+  if (ctx) ctx->set_err(std::string("bad argument: ") + what);
+  return ECCX_ERR_ARG;
+}
+int curve_err(eccx_ctx* ctx) {
+  if (ctx) ctx->set_err("unknown curve id");
+  return ECCX_ERR_CURVE;
+}
 
 // Persistent grid: the variable-base kernel keeps a 16-row window table per lane in a
 // scratch slab indexed by workgroup, so the grid is capped at a few workgroups per CU
@@ -130,8 +141,27 @@ int flat_grid(const eccx_ctx* ctx, size_t n) {
 // normalisation where the curve has one.
 int launch_var(eccx_ctx* ctx, const CurveOps* ops, size_t n, const uint8_t* d_scalars, const uint8_t* d_points,
                uint8_t* d_out, uint8_t* d_flags, uint8_t* d_proj, uint32_t kopts, bool mirror, hipStream_t s,
-               bool glv = false) {
+               bool glv = false, bool ct = false) {
   if (n == 0) return ECCX_OK;
+  if (ct && ops->var_ct && !d_proj && d_points && !(kopts & (K_OUT_TABLE | K_BASE_IS_GENERATOR))) {
+    // secret scalars, Weierstrass: the affine-table ladder that reads every table row at every lookup and
+    // resolves its special cases by selects (kernels_coz.hpp, CT = true).  Units it marks -- from the BASE POINT
+    // alone: order <= 2^(WB-1), or not a curve point -- are skipped by the normalisation and redone by the
+    // reference-mirroring ladder with the scan (complete formulas), which writes their bytes itself.
+    const int grid = ops->var_ct_grid(ctx->cus, n);
+    const int grid2 = std::min(ops->var_grid ? ops->var_grid(ctx->cus, n) : grid_for(ctx, n), ctx->cus);
+    int rc = ensure_scratch(ctx, ops->coz_row_words, grid);
+    if (rc) return rc;
+    rc = ensure_scratch(ctx, ops->info.row_words, grid2);
+    if (rc) return rc;
+    rc = ensure_rows(ctx, ops, n);
+    if (rc) return rc;
+    HIP_TRY(ctx, ops->var_ct(grid, s, n, d_scalars, d_points, ctx->jac, d_flags, ctx->scratch, kopts & ~K_CT_SCAN));
+    HIP_TRY(ctx, ops->to_affine_var(norm_grid(ctx, n), s, n, ctx->jac, d_out, d_flags));
+    HIP_TRY(ctx, ops->var(grid2, s, n, d_scalars, d_points, d_out, d_flags, nullptr, ctx->scratch,
+                          (kopts & K_VALIDATE) | K_CT_SCAN | K_ONLY_MARKED));
+    return ECCX_OK;
+  }
   const bool fast = !mirror && ops->var_fast && !d_proj && !(kopts & K_OUT_TABLE);
   if (fast && ops->var_coz && d_points && !(kopts & K_BASE_IS_GENERATOR)) {
     // Weierstrass curves: the ladder over an affine window table (kernels_coz.hpp); glv: bases known to be in the
@@ -213,14 +243,15 @@ struct DevMem {
   }
 };
 
-// `caller`: the stream the call that needs the table was made on.  The build runs on the context's
-// own stream and uses the context's scratch slab and row buffer, which an earlier call still
-// running on `caller` may be using: the build is ordered after it (it blocks the host anyway --
-// eccx_prepare pays it up front).
+// The build runs on the context's own stream and uses the context's scratch slab and row buffer, which
+// work enqueued earlier -- on the caller's stream, or on any other stream when the call is eccx_prepare --
+// may still be using: the build waits for the whole device first (it blocks the host anyway; eccx_prepare
+// pays it up front).
 int ensure_comb(eccx_ctx* ctx, int curve, const CurveOps* ops, hipStream_t caller) {
   std::lock_guard<std::mutex> g(ctx->comb_mu);
   if (ctx->comb[curve]) return ECCX_OK;
-  HIP_TRY(ctx, hipStreamSynchronize(caller));
+  (void)caller;
+  HIP_TRY(ctx, hipDeviceSynchronize());
   int nw = 2 * ops->info.sb;
   size_t rows = (size_t)nw * 16;
   std::vector<uint8_t> k = comb_scalars(ops);
@@ -284,7 +315,8 @@ int ensure_comb(eccx_ctx* ctx, int curve, const CurveOps* ops, hipStream_t calle
 int ensure_comb_lds(eccx_ctx* ctx, int curve, const CurveOps* ops, hipStream_t caller) {
   std::lock_guard<std::mutex> g(ctx->comb_mu);
   if (ctx->comb_lds[curve]) return ECCX_OK;
-  HIP_TRY(ctx, hipStreamSynchronize(caller));  // as ensure_comb
+  (void)caller;
+  HIP_TRY(ctx, hipDeviceSynchronize());  // as ensure_comb
   const int sbytes = ops->info.sb;
   const size_t entries = (size_t)ops->lds_windows * ops->lds_digits, pb = 2 * (size_t)ops->info.fb;
   std::vector<uint8_t> k(entries * sbytes, 0);
@@ -318,6 +350,64 @@ int ensure_comb_lds(eccx_ctx* ctx, int curve, const CurveOps* ops, hipStream_t c
   return ECCX_OK;
 }
 
+// table of the secret-scalar fixed-base kernels (kernels_ct.hpp): entry (w, d) = d * 2^(ct_bits * w) * G for
+// d = 1 .. ct_entries, built by the engine's own variable-base path (the generator is public; digits the top
+// window cannot produce get the zero scalar and stay unused)
+int ensure_comb_ct(eccx_ctx* ctx, int curve, const CurveOps* ops, hipStream_t caller) {
+  std::lock_guard<std::mutex> g(ctx->comb_mu);
+  if (ctx->comb_ct[curve]) return ECCX_OK;
+  if (!ops->base_ct || !ops->ct_convert) {
+    ctx->set_err("no secret-scalar fixed-base kernel for this curve");
+    return ECCX_ERR_ARG;
+  }
+  (void)caller;
+  HIP_TRY(ctx, hipDeviceSynchronize());  // as ensure_comb
+  const int sbytes = ops->info.sb, W = ops->ct_bits;
+  const size_t entries = (size_t)ops->ct_windows * ops->ct_entries, pb = 2 * (size_t)ops->info.fb;
+  // one more row: 2^(8 SB - 1) * G, from which the one reachable entry whose scalar does not fit SB bytes is made
+  // below -- the top window's digit 2^(8 SB - W w_top) stands for 2^(8 SB) * G (a scalar of all ones recodes to it)
+  std::vector<uint8_t> k((entries + 1) * sbytes, 0);
+  for (int w = 0; w < ops->ct_windows; ++w)
+    for (int d = 1; d <= ops->ct_entries; ++d) {
+      uint8_t* row = k.data() + ((size_t)w * ops->ct_entries + (size_t)(d - 1)) * sbytes;
+      bool fits = true;
+      for (int bit = 0; bit < 16; ++bit)
+        if ((d >> bit) & 1) {
+          const int pos = w * W + bit;
+          if (pos >= 8 * sbytes) { fits = false; break; }
+          row[sbytes - 1 - (pos >> 3)] |= (uint8_t)(1u << (pos & 7));
+        }
+      if (!fits) std::fill(row, row + sbytes, (uint8_t)0);
+    }
+  k[entries * sbytes] = 0x80;
+  DevMem mem;
+  uint8_t *d_k = nullptr, *d_aff = nullptr, *d_fl = nullptr;
+  uint32_t* d_tab = nullptr;
+  const size_t tab_bytes = entries * (size_t)ops->ct_entry_words * sizeof(uint32_t);
+  HIP_TRY(ctx, mem.alloc(&d_k, k.size()));
+  HIP_TRY(ctx, mem.alloc(&d_aff, (entries + 1) * pb));
+  HIP_TRY(ctx, mem.alloc(&d_fl, entries + 1));
+  HIP_TRY(ctx, mem.alloc(&d_tab, tab_bytes));
+  HIP_TRY(ctx, hipMemcpyAsync(d_k, k.data(), k.size(), hipMemcpyHostToDevice, ctx->stream));
+  int rc = launch_var(ctx, ops, entries + 1, d_k, nullptr, d_aff, d_fl, nullptr, K_BASE_IS_GENERATOR, false, ctx->stream);
+  if (rc) return rc;
+  {
+    const int w_top = ops->ct_windows - 1, shift = 8 * sbytes - W * w_top;  // 2^(8 SB) = 2^shift * 2^(W w_top)
+    if (shift >= 0 && shift < W && (1 << shift) <= ops->ct_entries) {
+      const size_t slot = (size_t)w_top * ops->ct_entries + (size_t)((1 << shift) - 1);
+      rc = eccx_point_add_dev(ctx, curve, 1, d_aff + entries * pb, nullptr, d_aff + entries * pb, nullptr, d_aff + slot * pb,
+                              d_fl + slot, 0, ctx->stream);  // the complete addition doubles
+      if (rc) return rc;
+    }
+  }
+  HIP_TRY(ctx, ops->ct_convert(ctx->stream, entries, d_aff, d_tab));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  mem.release(d_tab);
+  ctx->comb_ct[curve] = d_tab;
+  ctx->table_bytes += tab_bytes;
+  return ECCX_OK;
+}
+
 uint32_t kopts_of(uint32_t opts) { return (opts & ECCX_VALIDATE_POINTS) ? K_VALIDATE : 0u; }
 
 size_t proj_bytes(const CurveOps* ops) { return (size_t)(ops->info.edwards ? 4 : 3) * ops->info.fb; }
@@ -327,9 +417,9 @@ int run_host(eccx_ctx* ctx, int curve, bool base, size_t n, const uint8_t* scala
              uint8_t* out, uint8_t* flags, uint8_t* proj, uint32_t opts) {
   const CurveOps* ops = ops_of(curve);
   if (!ctx) return ECCX_ERR_ARG;
-  if (!ops) return ECCX_ERR_CURVE;
+  if (!ops) return curve_err(ctx);
   if (n == 0) return ECCX_OK;
-  if (!scalars || !out || !flags || (!base && !points)) return ECCX_ERR_ARG;
+  if (!scalars || !out || !flags || (!base && !points)) return arg_err(ctx, "null buffer");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   size_t sb = ops->info.sb, pb = 2 * (size_t)ops->info.fb;
   uint8_t *d_k = nullptr, *d_p = nullptr, *d_o = nullptr, *d_f = nullptr, *d_j = nullptr;
@@ -500,6 +590,8 @@ void eccx_shutdown(eccx_ctx* ctx) {
     if (t) (void)hipFree(t);
   for (auto& t : ctx->comb_lds)
     if (t) (void)hipFree(t);
+  for (auto& t : ctx->comb_ct)
+    if (t) (void)hipFree(t);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->jac) (void)hipFree(ctx->jac);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -532,21 +624,25 @@ const char* eccx_strerror(int code) {
 int eccx_prepare(eccx_ctx* ctx, int curve, uint32_t what) {
   const CurveOps* ops = ops_of(curve);
   if (!ctx) return ECCX_ERR_ARG;
-  if (!ops) return ECCX_ERR_CURVE;
+  if (!ops) return curve_err(ctx);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   int rc = ECCX_OK;
   if (what & ECCX_PREP_BASE) rc = ensure_comb(ctx, curve, ops, ctx->stream);
   if (!rc && (what & ECCX_PREP_BASE_LDS)) {
-    if (!ops->base_lds || !ops->lds_convert) return ECCX_ERR_ARG;
+    if (!ops->base_lds || !ops->lds_convert) {
+      ctx->set_err("ECCX_PREP_BASE_LDS: this curve has no LDS-resident fixed-base kernel (edwards25519 only)");
+      return ECCX_ERR_ARG;
+    }
     rc = ensure_comb_lds(ctx, curve, ops, ctx->stream);
   }
+  if (!rc && (what & ECCX_PREP_CT)) rc = ensure_comb_ct(ctx, curve, ops, ctx->stream);
   return rc;
 }
 
 int eccx_reserve(eccx_ctx* ctx, int curve, size_t max_n, uint32_t what) {
   const CurveOps* ops = ops_of(curve);
   if (!ctx) return ECCX_ERR_ARG;
-  if (!ops) return ECCX_ERR_CURVE;
+  if (!ops) return curve_err(ctx);
   if (max_n == 0) return ECCX_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   int rc = ensure_rows(ctx, ops, max_n);  // every entry point writes un-normalised rows first
@@ -562,7 +658,16 @@ int eccx_reserve(eccx_ctx* ctx, int curve, size_t max_n, uint32_t what) {
       if (rc) return rc;
     }
   }
-  if ((what & ECCX_PREP_MIRROR) && ops->info.row_words) {  // slab of the reference-mirroring ladder
+  if ((what & ECCX_PREP_CT) && ops->var_ct) {  // secret scalars: the scanning affine-table ladder + its fix-up
+    rc = ensure_scratch(ctx, ops->coz_row_words, ops->var_ct_grid(ctx->cus, max_n));
+    if (rc) return rc;
+    const int grid2 = std::min(ops->var_grid ? ops->var_grid(ctx->cus, max_n) : grid_for(ctx, max_n), ctx->cus);
+    rc = ensure_scratch(ctx, ops->info.row_words, grid2);
+    if (rc) return rc;
+  }
+  // slab of the reference-mirroring ladder (also what ECCX_CT_SCAN runs on a curve without a scanning fast ladder)
+  const bool mirror_slab = (what & ECCX_PREP_MIRROR) || ((what & ECCX_PREP_CT) && !ops->var_ct);
+  if (mirror_slab && ops->info.row_words) {
     const int grid = ops->var_grid ? ops->var_grid(ctx->cus, max_n) : grid_for(ctx, max_n);
     rc = ensure_scratch(ctx, ops->info.row_words, grid);
     if (rc) return rc;
@@ -582,32 +687,57 @@ int eccx_scalarmul_var_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_sca
                            void* d_out, void* d_flags, void* d_proj, uint32_t opts, void* stream) {
   const CurveOps* ops = ops_of(curve);
   if (!ctx) return ECCX_ERR_ARG;
-  if (!ops) return ECCX_ERR_CURVE;
+  if (!ops) return curve_err(ctx);
   if (n == 0) return ECCX_OK;
-  if (!d_scalars || !d_points || !d_out || !d_flags) return ECCX_ERR_ARG;
+  if (!d_scalars || !d_points || !d_out || !d_flags) return arg_err(ctx, "null buffer");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = static_cast<hipStream_t>(stream);  // NULL = HIP's default stream
   // ECCX_CT_SCAN: the reference-mirroring ladder (complete formulas, no data-dependent branch) with
   // select_from_table's full scan; edwards25519's mirror ladder is bit-serial and has no table
   const bool ct = (opts & ECCX_CT_SCAN) != 0;
+  if (ct && (opts & ECCX_ASSUME_SUBGROUP)) {
+    ctx->set_err("ECCX_CT_SCAN | ECCX_ASSUME_SUBGROUP: the endomorphism ladder has no secret-scalar form");
+    return ECCX_ERR_ARG;
+  }
+  // secret scalars: the scanning affine-table ladder where the curve has one (Weierstrass), unless the
+  // reference-mirroring kernels are asked for (ECCX_MIRROR_REFERENCE, proj): those scan as the reference does
+  const bool ct_fast = ct && !(opts & ECCX_MIRROR_REFERENCE) && !d_proj && ops->var_ct;
   return launch_var(ctx, ops, n, static_cast<const uint8_t*>(d_scalars), static_cast<const uint8_t*>(d_points),
                     static_cast<uint8_t*>(d_out), static_cast<uint8_t*>(d_flags), static_cast<uint8_t*>(d_proj),
                     kopts_of(opts) | (ct ? K_CT_SCAN : 0u), ct || (opts & ECCX_MIRROR_REFERENCE) != 0, s,
-                    (opts & ECCX_ASSUME_SUBGROUP) != 0);
+                    (opts & ECCX_ASSUME_SUBGROUP) != 0, ct_fast);
 }
 
 int eccx_scalarmul_base_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_scalars, void* d_out, void* d_flags,
                             void* d_proj, uint32_t opts, void* stream) {
   const CurveOps* ops = ops_of(curve);
   if (!ctx) return ECCX_ERR_ARG;
-  if (!ops) return ECCX_ERR_CURVE;
+  if (!ops) return curve_err(ctx);
   if (n == 0) return ECCX_OK;
-  if (!d_scalars || !d_out || !d_flags) return ECCX_ERR_ARG;
+  if (!d_scalars || !d_out || !d_flags) return arg_err(ctx, "null buffer");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = static_cast<hipStream_t>(stream);  // NULL = HIP's default stream
-  int rc = ensure_comb(ctx, curve, ops, s);
-  if (rc) return rc;
+  int rc = ECCX_OK;
   size_t need = (n + eccx::LAUNCH_WG - 1) / eccx::LAUNCH_WG;
+  if ((opts & ECCX_CT_SCAN) && !(opts & (ECCX_MIRROR_REFERENCE | ECCX_TABLE_IN_L2)) && !d_proj && ops->base_ct) {
+    // secret scalars: signed windows, every entry of a window read by every lane (kernels_ct.hpp)
+    if (opts & ECCX_TABLE_IN_LDS) {
+      ctx->set_err("ECCX_CT_SCAN | ECCX_TABLE_IN_LDS: the LDS-resident comb indexes its table by the digit");
+      return ECCX_ERR_ARG;
+    }
+    rc = ensure_comb_ct(ctx, curve, ops, s);
+    if (rc) return rc;
+    rc = ensure_rows(ctx, ops, n);
+    if (rc) return rc;
+    const int cgrid = (int)std::max<size_t>(1, std::min(need, (size_t)ctx->cus * 16));
+    HIP_TRY(ctx, ops->base_ct(cgrid, s, n, static_cast<const uint8_t*>(d_scalars), ctx->comb_ct[curve], ctx->jac,
+                              static_cast<uint8_t*>(d_flags)));
+    HIP_TRY(ctx, ops->to_affine_var(norm_grid(ctx, n), s, n, ctx->jac, static_cast<uint8_t*>(d_out),
+                                    static_cast<uint8_t*>(d_flags)));
+    return ECCX_OK;
+  }
+  rc = ensure_comb(ctx, curve, ops, s);
+  if (rc) return rc;
   // up to 16 workgroups per CU: at 2^20 units every lane then takes ONE unit and the hardware's dispatcher
   // balances the tail (measured against 8 and 4 per CU: Ed25519 0.733 / 0.747 / 0.768 ms, P-256 1.110 / 1.126 / 1.142)
   int grid = (int)std::max<size_t>(1, std::min(need, (size_t)ctx->cus * 16));
@@ -668,9 +798,9 @@ int eccx_point_add_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_a, cons
                        const void* d_b_inf, void* d_out, void* d_flags, uint32_t opts, void* stream) {
   const CurveOps* ops = ops_of(curve);
   if (!ctx) return ECCX_ERR_ARG;
-  if (!ops) return ECCX_ERR_CURVE;
+  if (!ops) return curve_err(ctx);
   if (n == 0) return ECCX_OK;
-  if (!d_a || !d_b || !d_out || !d_flags) return ECCX_ERR_ARG;
+  if (!d_a || !d_b || !d_out || !d_flags) return arg_err(ctx, "null buffer");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc = ensure_rows(ctx, ops, n);
@@ -690,9 +820,9 @@ int eccx_point_add(eccx_ctx* ctx, int curve, size_t n, const uint8_t* a, const u
                    const uint8_t* b_inf, uint8_t* out, uint8_t* flags, uint32_t opts) {
   const CurveOps* ops = ops_of(curve);
   if (!ctx) return ECCX_ERR_ARG;
-  if (!ops) return ECCX_ERR_CURVE;
+  if (!ops) return curve_err(ctx);
   if (n == 0) return ECCX_OK;
-  if (!a || !b || !out || !flags) return ECCX_ERR_ARG;
+  if (!a || !b || !out || !flags) return arg_err(ctx, "null buffer");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const size_t pb = 2 * (size_t)ops->info.fb;
   DevMem mem;
@@ -724,17 +854,17 @@ int eccx_point_decompress_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_
                               uint32_t opts, void* stream) {
   const CurveOps* ops = ops_of(curve);
   if (!ctx) return ECCX_ERR_ARG;
-  if (!ops) return ECCX_ERR_CURVE;
+  if (!ops) return curve_err(ctx);
   if (n == 0) return ECCX_OK;
-  if (!d_enc || !d_out || !d_flags) return ECCX_ERR_ARG;
+  if (!d_enc || !d_out || !d_flags) return arg_err(ctx, "null buffer");
   // the sec2 curves have cofactor 1 (nothing to check); decode_point makes no such test
-  if ((opts & ECCX_CHECK_SUBGROUP) && ops->info.edwards) return ECCX_ERR_ARG;
+  if ((opts & ECCX_CHECK_SUBGROUP) && ops->info.edwards) return arg_err(ctx, "ECCX_CHECK_SUBGROUP: edwards25519 decoding makes no subgroup test");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
   uint8_t* out = static_cast<uint8_t*>(d_out);
   uint8_t* flags = static_cast<uint8_t*>(d_flags);
   if (opts & ECCX_UNCOMPRESSED) {
-    if (!ops->decompress_raw) return ECCX_ERR_ARG;  // the flavour exists for bls12_381_g1 only
+    if (!ops->decompress_raw) return arg_err(ctx, "ECCX_UNCOMPRESSED: the flavour exists for bls12_381_g1 only");
     HIP_TRY(ctx, ops->decompress_raw(flat_grid(ctx, n), s, n, static_cast<const uint8_t*>(d_enc), out, flags));
   } else {
     HIP_TRY(ctx, ops->decompress(flat_grid(ctx, n), s, n, static_cast<const uint8_t*>(d_enc), out, flags));
@@ -751,11 +881,11 @@ int eccx_point_compress_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_xy
                             uint32_t opts, void* stream) {
   const CurveOps* ops = ops_of(curve);
   if (!ctx) return ECCX_ERR_ARG;
-  if (!ops) return ECCX_ERR_CURVE;
+  if (!ops) return curve_err(ctx);
   if (n == 0) return ECCX_OK;
-  if (!d_xy || !d_out) return ECCX_ERR_ARG;
+  if (!d_xy || !d_out) return arg_err(ctx, "null buffer");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if ((opts & ECCX_UNCOMPRESSED) && !ops->compress_raw) return ECCX_ERR_ARG;
+  if ((opts & ECCX_UNCOMPRESSED) && !ops->compress_raw) return arg_err(ctx, "ECCX_UNCOMPRESSED: the flavour exists for bls12_381_g1 only");
   HIP_TRY(ctx, ((opts & ECCX_UNCOMPRESSED) ? ops->compress_raw : ops->compress)(
                    flat_grid(ctx, n), static_cast<hipStream_t>(stream), n, static_cast<const uint8_t*>(d_xy),
                    static_cast<const uint8_t*>(d_inf), static_cast<uint8_t*>(d_out)));
@@ -766,9 +896,9 @@ int eccx_point_decompress(eccx_ctx* ctx, int curve, size_t n, const uint8_t* enc
                           uint32_t opts) {
   const CurveOps* ops = ops_of(curve);
   if (!ctx) return ECCX_ERR_ARG;
-  if (!ops) return ECCX_ERR_CURVE;
+  if (!ops) return curve_err(ctx);
   if (n == 0) return ECCX_OK;
-  if (!enc || !out || !flags) return ECCX_ERR_ARG;
+  if (!enc || !out || !flags) return arg_err(ctx, "null buffer");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const size_t pb = 2 * (size_t)ops->info.fb, eb = (opts & ECCX_UNCOMPRESSED) ? pb : (size_t)ops->enc_bytes;
   DevMem mem;
@@ -789,9 +919,9 @@ int eccx_point_compress(eccx_ctx* ctx, int curve, size_t n, const uint8_t* xy, c
                         uint32_t opts) {
   const CurveOps* ops = ops_of(curve);
   if (!ctx) return ECCX_ERR_ARG;
-  if (!ops) return ECCX_ERR_CURVE;
+  if (!ops) return curve_err(ctx);
   if (n == 0) return ECCX_OK;
-  if (!xy || !out) return ECCX_ERR_ARG;
+  if (!xy || !out) return arg_err(ctx, "null buffer");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const size_t pb = 2 * (size_t)ops->info.fb, eb = (opts & ECCX_UNCOMPRESSED) ? pb : (size_t)ops->enc_bytes;
   DevMem mem;
@@ -812,11 +942,17 @@ int eccx_double_scalarmul_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_
                               void* d_out, void* d_flags, uint32_t opts, void* stream) {
   const CurveOps* ops = ops_of(curve);
   if (!ctx) return ECCX_ERR_ARG;
-  if (!ops) return ECCX_ERR_CURVE;
+  if (!ops) return curve_err(ctx);
   if (n == 0) return ECCX_OK;
-  if (!d_u1 || !d_u2 || !d_q || !d_out || !d_flags) return ECCX_ERR_ARG;
-  if (!ops->var_fused || !ops->to_affine_var) return ECCX_ERR_ARG;
-  if (opts & ECCX_CT_SCAN) return ECCX_ERR_ARG;  // the verify shape works on public data; no scanning form
+  if (!d_u1 || !d_u2 || !d_q || !d_out || !d_flags) return arg_err(ctx, "null buffer");
+  if (!ops->var_fused || !ops->to_affine_var) {
+    ctx->set_err("eccx_double_scalarmul: no fused kernel for this curve");
+    return ECCX_ERR_ARG;
+  }
+  if (opts & ECCX_CT_SCAN) {  // the verify shape works on public data; no scanning form
+    ctx->set_err("eccx_double_scalarmul: ECCX_CT_SCAN is not accepted (signature verification handles public data)");
+    return ECCX_ERR_ARG;
+  }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   // one kernel: the ladder for u2*Q, then the 16-bit comb of u1*G onto the same point
   hipStream_t s = static_cast<hipStream_t>(stream);  // NULL = HIP's default stream
@@ -851,9 +987,9 @@ int eccx_double_scalarmul(eccx_ctx* ctx, int curve, size_t n, const uint8_t* u1,
                           const uint8_t* q, uint8_t* out, uint8_t* flags, uint32_t opts) {
   const CurveOps* ops = ops_of(curve);
   if (!ctx) return ECCX_ERR_ARG;
-  if (!ops) return ECCX_ERR_CURVE;
+  if (!ops) return curve_err(ctx);
   if (n == 0) return ECCX_OK;
-  if (!u1 || !u2 || !q || !out || !flags) return ECCX_ERR_ARG;
+  if (!u1 || !u2 || !q || !out || !flags) return arg_err(ctx, "null buffer");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const size_t pb = 2 * (size_t)ops->info.fb, sb = (size_t)ops->info.sb;
   DevMem mem;
@@ -878,7 +1014,7 @@ int eccx_x25519_dev(eccx_ctx* ctx, size_t n, const void* d_scalars, const void* 
                     uint32_t opts, void* stream) {
   if (!ctx) return ECCX_ERR_ARG;
   if (n == 0) return ECCX_OK;
-  if (!d_scalars || !d_out || !d_flags) return ECCX_ERR_ARG;
+  if (!d_scalars || !d_out || !d_flags) return arg_err(ctx, "null buffer");
   const CurveOps* ops = ops_of(ECCX_ED25519);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -899,7 +1035,7 @@ int eccx_x25519(eccx_ctx* ctx, size_t n, const uint8_t* scalars, const uint8_t* 
                 uint32_t opts) {
   if (!ctx) return ECCX_ERR_ARG;
   if (n == 0) return ECCX_OK;
-  if (!scalars || !out || !flags) return ECCX_ERR_ARG;
+  if (!scalars || !out || !flags) return arg_err(ctx, "null buffer");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   uint8_t *d_k = nullptr, *d_u = nullptr, *d_o = nullptr, *d_f = nullptr;
   auto cleanup = [&]() {
@@ -932,7 +1068,7 @@ int eccx_x25519(eccx_ctx* ctx, size_t n, const uint8_t* scalars, const uint8_t* 
 int eccx_comb_table(eccx_ctx* ctx, int curve, uint8_t* out) {
   const CurveOps* ops = ops_of(curve);
   if (!ctx || !out) return ECCX_ERR_ARG;
-  if (!ops) return ECCX_ERR_CURVE;
+  if (!ops) return curve_err(ctx);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   int nw = 2 * ops->info.sb;
   size_t rows = (size_t)nw * 16, pb = 2 * (size_t)ops->info.fb;

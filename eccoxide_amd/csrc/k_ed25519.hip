@@ -1,5 +1,6 @@
 // Kernel instantiations for edwards25519 (see kernels.hpp).
 #include "kernels_codec.hpp"
+#include "kernels_ct.hpp"
 #include "launch.hpp"
 
 namespace eccx {
@@ -91,6 +92,17 @@ hipError_t compress_(int grid, hipStream_t s, size_t n, const uint8_t* xy, const
   hipLaunchKernelGGL((k_point_compress<ED25519, FORMAT_RFC8032>), dim3(grid), dim3(WG), 0, s, n, xy, nullptr, out);
   return hipGetLastError();
 }
+// secret scalars (ECCX_CT_SCAN): signed windows, every entry of the window read (kernels_ct.hpp)
+hipError_t ct_convert_(hipStream_t s, size_t entries, const uint8_t* affine, uint32_t* table) {
+  hipLaunchKernelGGL(k_ed_affine_to_niels_unsat<ED25519U>, dim3((unsigned)((entries + 127) / 128)), dim3(128), 0, s, entries, affine,
+                     table, ct_entry_words<ED25519U>());
+  return hipGetLastError();
+}
+hipError_t base_ct_(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint32_t* table, uint32_t* rows,
+                    uint8_t* flags) {
+  hipLaunchKernelGGL(k_ed_scalarmul_base_ct<ED25519U>, dim3(grid), dim3(WG), 0, s, n, scalars, table, rows, flags);
+  return hipGetLastError();
+}
 }  // namespace
 hipError_t launch_x25519_ladder(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint8_t* u, uint32_t* rows,
                                 uint8_t* flags, uint32_t opts) {
@@ -103,9 +115,18 @@ hipError_t launch_x25519_to_u(int grid, hipStream_t s, size_t n, const uint32_t*
   return hipGetLastError();
 }
 const CurveOps& ops_ED25519() {
-  static const CurveOps o = {{ED25519::FB, ED25519::SB, ED25519::L, 4 * ED25519::L, 0, 1, ED_VAR_ROW_WORDS,
+  static const CurveOps o = [] {
+    CurveOps t = {{ED25519::FB, ED25519::SB, ED25519::L, 4 * ED25519::L, 0, 1, ED_VAR_ROW_WORDS,
                               (urow3_words<ED25519U>() > row_words<ED25519::L>() ? urow3_words<ED25519U>() : row_words<ED25519::L>())}, var_, base_, var_fast_, base_lds_, to_affine_hom_, var_grid_, var_fast_grid_, to_affine_var_, point_add_, ED_U_ENTRY_WORDS, comb_bits<ED25519U>(), comb_convert_, base_w8_, ED_LDS_BITS, ED_LDS_WINDOWS, ED_LDS_DIGITS, ED_LDS_ENTRY_WORDS, lds_convert_, var_fused_, 32, decompress_, compress_, nullptr, nullptr,
                               point_add_u_, to_affine_add_u_};
+    t.ct_bits = ct_base_bits<ED25519U>();
+    t.ct_windows = ct_base_windows<ED25519U>();
+    t.ct_entries = ct_base_entries<ED25519U>();
+    t.ct_entry_words = ct_entry_words<ED25519U>();
+    t.ct_convert = ct_convert_;
+    t.base_ct = base_ct_;
+    return t;
+  }();
   return o;
 }
 }  // namespace eccx

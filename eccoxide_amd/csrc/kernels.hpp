@@ -30,6 +30,10 @@ enum : uint32_t {
 };
 
 constexpr int WG = 256;
+// flag value of a unit the affine-table ladder could not finish (base point of order <= 16, or not a curve
+// point at all): it is redone by the kernel launched behind with OPT_ONLY_MARKED, and skipped by the
+// normalisation in between
+constexpr uint8_t FLAG_REDO = 0xFE;
 
 template <int L>
 constexpr int row_words() { return ((3 * L + 3) / 4) * 4; }  // padded to 16 bytes

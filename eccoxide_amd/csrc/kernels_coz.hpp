@@ -14,7 +14,7 @@
 // this kernel marks as degenerate.
 #pragma once
 #include "inv_gcd.hpp"
-#include "kernels_unsat.hpp"
+#include "kernels_ct.hpp"
 
 namespace eccx {
 
@@ -120,7 +120,6 @@ ECCX_DEV void glv_split(uint32_t (&k1)[5], uint32_t (&k2)[5], const uint8_t* __r
 // a ratio is zero): such units are only MARKED here (flag FLAG_REDO) and recomputed by the generic
 // ladder, launched behind this kernel with OPT_ONLY_MARKED -- no point of a prime-order curve and no
 // valid G1 point takes that path.
-constexpr uint8_t FLAG_REDO = 0xFE;
 
 template <class CU>
 constexpr int urowc_words() { return ((3 * CU::N + 3) / 4) * 4; }
@@ -196,6 +195,93 @@ ECCX_DEV void uzaddu(U<CU, 1, 3>& x1, U<CU, 1, 3>& y1, U<CU, 1, 3>& x2, U<CU, 1,
   d_out = d;
 }
 
+// r = p + (x2, y2, 1) with y2 already signed; h_zero / r_zero without early exits (secret-scalar form)
+template <class CU>
+ECCX_DEV void ujac_madd_ct(UJac<CU>& r, bool& h_zero, bool& r_zero, const UJac<CU>& p, const U<CU, 1, 3>& x2,
+                           const U<CU, 1, 3>& y2) {
+  auto z1z1 = u_sqr(p.z);
+  auto u2 = u_mul(x2, z1z1);
+  auto t = u_mul(p.z, z1z1);
+  auto s2 = u_mul(y2, t);
+  auto h = u_reduce(u_sub(u2, p.x));
+  auto rr = u_reduce(u_sub(s2, p.y));
+  h_zero = u_is_zero_mod_p_ct(h);
+  r_zero = u_is_zero_mod_p_ct(rr);
+  auto hh = u_sqr(h);
+  auto hhh = u_mul(h, hh);
+  auto v = u_mul(p.x, hh);
+  auto r2 = u_sqr(rr);
+  auto x3 = u_reduce(u_sub(u_sub(u_sub(r2, hhh), v), v));
+  r.x = x3;
+  if constexpr (CU::KIND == UK_MONT) {
+    r.y = u_fit<1, 3>(u_mul_add(rr, u_sub(v, x3), u_neg(p.y), hhh));
+  } else if constexpr (UB<CU>::SPARSE) {
+    r.y = u_mul_sub(rr, u_sub(v, x3), p.y, hhh);
+  } else {
+    auto y3a = u_mul(rr, u_sub(v, x3));
+    auto y1h = u_mul(p.y, hhh);
+    r.y = u_reduce(u_sub(y3a, y1h));
+  }
+  r.z = u_fit<UJac<CU>::ZK, UJac<CU>::ZV>(u_mul(p.z, h));
+}
+
+// 2 (x, y) from AFFINE coordinates, Jacobian result with Z3 = 2 y (2 products + 4 squares).  As a by-product
+// S = 4 x y^2 and 8 y^4 are (x, y) itself over the denominator 2 y -- what the co-Z table build starts from.
+template <class CU>
+ECCX_DEV void ujac_dbl_affine(U<CU, 1, 3>& x3, U<CU, 1, 3>& y3, U<CU, 1, 3>& z3, U<CU, 1, 3>& sv, U<CU, 1, 3>& y8v,
+                              const U<CU, 1, 3>& px, const U<CU, 1, 3>& py) {
+  const auto xx = u_sqr(px);
+  const auto yy = u_sqr(py);
+  const auto yyyy = u_sqr(yy);
+  const auto xyy = u_mul(px, yy);
+  const auto s2 = u_add(xyy, xyy);
+  sv = u_reduce(u_add(s2, s2));
+  const auto y4 = u_add(yyyy, yyyy);
+  const auto y8 = u_add(y4, y4);
+  y8v = u_reduce(u_add(y8, y8));
+  if constexpr (CU::Sat::A0 == 1) {
+    const auto m = u_reduce(u_add(u_add(xx, xx), xx));  // 3 x^2
+    x3 = u_reduce(u_sub(u_sub(u_sqr(m), sv), sv));
+    y3 = u_reduce(u_sub(u_mul(m, u_sub(sv, x3)), y8v));
+  } else {
+    U<CU, 1, 3> one;
+#pragma unroll
+    for (int i = 0; i < CU::N; ++i) one.v[i] = CU::ONE[i];
+    const auto xm = u_sub(xx, one);                      // a = -3: 3 (x^2 - 1)
+    const auto m = u_reduce(u_add(u_add(xm, xm), xm));
+    x3 = u_reduce(u_sub(u_sub(u_sqr(m), sv), sv));
+    y3 = u_reduce(u_sub(u_mul(m, u_sub(sv, x3)), y8v));
+  }
+  z3 = u_reduce(u_add(py, py));
+}
+
+// Secret scalars (CT = true, ECCX_CT_SCAN).  Same ladder; what changes:
+//   lookup      every row 1 .. 2^(WB-1) of the lane's table is read and the digit's row kept by v_cndmask
+//               (select_from_table, src/curve/projective.rs:427-434): no address depends on a digit.  The
+//               table is private to the lane (HBM slab), so the scan multiplies its traffic by the number
+//               of rows: the secret-scalar form uses narrower windows (WB = 4: 8 rows, 65 additions for 256
+//               bits) than the default (WB = 5: 16 rows, 52 additions).
+//   branches    none on scalar-derived data: the accumulator-at-infinity patch runs unconditionally, and
+//               accumulator == +-entry is resolved by selects -- -entry: infinity; entry: 2 * entry computed
+//               from the entry's affine coordinates (ujac_dbl_affine).  Before window w (5 doublings done)
+//               the accumulator is 2^WB S P with |S| <= k / 2^(WB (w + 1)) + 0.6 and the entry is d P with
+//               |d| <= 2^(WB-1): on a point of prime order n, 2^WB S = +-d (mod n) needs
+//               2^(WB w) <= 2^(8 SB) / (n - 35), i.e. w <= (8 SB - NBITS + 1) / WB.  Only those bottom windows
+//               (coz_full_windows(): 1, P-521: 2-3) compute the doubling; curves with a cofactor
+//               (BLS12-381: points of order 33, 121, ... exist) compute it in every window.
+//   what still depends on data: the BASE POINT (public in every protocol the reference implements):
+//               rejected / degenerate units are flagged from the point alone and redone by the
+//               reference-mirroring scan kernel.
+template <class CU, int WB>
+constexpr int coz_full_windows() {
+  using CS = typename CU::Sat;
+  constexpr int NWIN = (8 * CS::SB + 1 + WB - 1) / WB;
+  return CS::PRIME_ORDER ? (8 * CS::SB - CS::NBITS + 1) / WB + 1 : NWIN;
+}
+#ifndef ECCX_CT_VAR_BITS
+#define ECCX_CT_VAR_BITS 4
+#endif
+
 // Waves per SIMD the kernel is compiled for: the mixed additions keep two coordinates of an entry live where
 // the generic ladder keeps five, so the 14-limb fields fit three waves (measured against two: P-384 19.49 ->
 // 18.67 ms, BLS12-381 34.55 -> 34.07 ms; the generic 14-limb ladder was 8 % SLOWER at three, and the GLV form,
@@ -214,7 +300,7 @@ constexpr int coz_occupancy() { return CU::N <= 9 ? ECCX_COZ_OCC_U9 : (CU::N <= 
 // zeta (words 16..16+N); rows 1..16: the table.
 // FUSED: the verify shape u1*G + u2*Q (u1*G - u2*Q with OPT_NEGATE_B; src/protocol/ecdsa.rs:215) in one pass, as in
 // k_scalarmul_var_unsat<CU, true>: the ladder computes u2*(+-Q), the 16-bit comb of u1*G is accumulated onto it.
-template <class CU, class G, bool GLV, bool FUSED = false>
+template <class CU, class G, bool GLV, bool FUSED = false, int WB = 5, bool CT = false>
 __global__ void __launch_bounds__(WG, (coz_occupancy<CU, GLV>())) k_scalarmul_coz_unsat(size_t n, const uint8_t* __restrict__ scalars,
                                                                                  const uint8_t* __restrict__ points,
                                                                                  uint32_t* __restrict__ rows_out,
@@ -223,6 +309,9 @@ __global__ void __launch_bounds__(WG, (coz_occupancy<CU, GLV>())) k_scalarmul_co
                                                                                  const uint8_t* __restrict__ base_scalars = nullptr,
                                                                                  const uint32_t* __restrict__ utable = nullptr) {
   static_assert(!(GLV && FUSED), "the verify shape takes any curve point");
+  static_assert(!(CT && (GLV || FUSED)), "the secret-scalar form is the plain ladder");
+  static_assert(WB >= 3 && WB <= 5, "table rows 1 .. 2^(WB-1) must fit the slab");
+  constexpr int TBL = 1 << (WB - 1);  // table rows 1 .. TBL
   using CS = typename CU::Sat;
   constexpr bool ISO = CS::A0 == 1;  // a = 0: isomorphic curve, no inversion
   constexpr int L = CS::L;
@@ -230,7 +319,7 @@ __global__ void __launch_bounds__(WG, (coz_occupancy<CU, GLV>())) k_scalarmul_co
   constexpr int FB = CS::FB;
   constexpr int SB = CS::SB;
   static_assert(!GLV || SB == 32, "the split is written for 256-bit scalars");
-  constexpr int NWIN = GLV ? (G::K_BITS + 1 + 4) / 5 : (8 * SB + 1 + 4) / 5;
+  constexpr int NWIN = GLV ? (G::K_BITS + 1 + WB - 1) / WB : (8 * SB + 1 + WB - 1) / WB;
   constexpr int WR = urowc_words<CU>();
   static_assert(!ISO || WR >= 16 + N, "row 0 holds the split scalar and zeta");
   using T = U<CU, 1, 3>;
@@ -282,22 +371,18 @@ __global__ void __launch_bounds__(WG, (coz_occupancy<CU, GLV>())) k_scalarmul_co
       uint32_t w6;
       if constexpr (GLV) {
         const uint32_t* __restrict__ h = kw + (second ? 8 : 0);
-        const int pos = 5 * w - 1 + 32;  // one zero word below the scalar
+        const int pos = WB * w - 1 + 32;  // one zero word below the scalar
         const int wi = pos >> 5, sh = pos & 31;
         const uint32_t lo = (wi >= 1 && wi <= 5) ? h[wi - 1] : 0u;
         const uint32_t hi = (wi <= 4) ? h[wi] : 0u;
-        w6 = (uint32_t)((((uint64_t)hi << 32) | lo) >> sh) & 0x3fu;
+        w6 = (uint32_t)((((uint64_t)hi << 32) | lo) >> sh) & ((1u << (WB + 1)) - 1u);
+        const uint32_t s = ~((w6 >> WB) - 1u);
+        const uint32_t m = (((1u << (WB + 1)) - w6 - 1u) & s) | (w6 & ~s);
+        d = (m >> 1) + (m & 1u);
+        neg = (s & 1u) != 0;
       } else {
-        const int pos = 5 * w - 1 + 8;
-        const int bi = pos >> 3;
-        const uint32_t b0 = (bi >= 1 && bi <= SB) ? k[SB - bi] : 0u;
-        const uint32_t b1 = (bi + 1 <= SB) ? k[SB - bi - 1] : 0u;
-        w6 = ((b0 | (b1 << 8)) >> (pos & 7)) & 0x3fu;
+        booth_digit<WB, SB>(k, w, d, neg);
       }
-      const uint32_t s = ~((w6 >> 5) - 1u);
-      const uint32_t m = (((1u << 6) - w6 - 1u) & s) | (w6 & ~s);
-      d = (m >> 1) + (m & 1u);
-      neg = (s & 1u) != 0;
     };
 
     // ---- table build: rows d = 1..16 hold (X_d, Y_d, Z_d / Z_{d-1}), each over the denominator of its step ----
@@ -308,27 +393,8 @@ __global__ void __launch_bounds__(WG, (coz_occupancy<CU, GLV>())) k_scalarmul_co
       T zacc = one;          // Z_d (a = -3 only: a = 0 gets zeta as the product of the ratios)
       {
         // 2P from the affine P, co-Z with P for free: S = 4 x y^2 and 8 y^4 are P's coordinates over Z_2 = 2 y
-        const auto xx = u_sqr(px);
-        const auto yy = u_sqr(py);
-        const auto yyyy = u_sqr(yy);
-        const auto xyy = u_mul(px, yy);
-        const auto s2 = u_add(xyy, xyy);
-        const T sv = u_reduce(u_add(s2, s2));
-        const auto y4 = u_add(yyyy, yyyy);
-        const auto y8 = u_add(y4, y4);
-        const T y8v = u_reduce(u_add(y8, y8));
-        T x3, y3;
-        if constexpr (ISO) {
-          const auto m = u_reduce(u_add(u_add(xx, xx), xx));  // 3 x^2
-          x3 = u_reduce(u_sub(u_sub(u_sqr(m), sv), sv));
-          y3 = u_reduce(u_sub(u_mul(m, u_sub(sv, x3)), y8v));
-        } else {
-          const auto xm = u_sub(xx, one);                      // a = -3: 3 (x^2 - 1)
-          const auto m = u_reduce(u_add(u_add(xm, xm), xm));
-          x3 = u_reduce(u_sub(u_sub(u_sqr(m), sv), sv));
-          y3 = u_reduce(u_sub(u_mul(m, u_sub(sv, x3)), y8v));
-        }
-        ratio = u_reduce(u_add(py, py));
+        T x3, y3, sv, y8v;
+        ujac_dbl_affine<CU>(x3, y3, ratio, sv, y8v, px, py);
         degenerate = u_is_zero_mod_p(ratio);
         tx = x3;
         ty = y3;
@@ -337,17 +403,17 @@ __global__ void __launch_bounds__(WG, (coz_occupancy<CU, GLV>())) k_scalarmul_co
         if constexpr (!ISO) zacc = ratio;
         u3_store<CU>(row(2), tx, ty, ratio);
       }
-      for (int d = 3; d <= 16; ++d) {
+      for (int d = 3; d <= TBL; ++d) {
         bool dz;
         uzaddu<CU>(px, py, tx, ty, ratio, dz);  // T_d = P + T_{d-1}
         degenerate = degenerate || dz;
         if constexpr (!ISO) zacc = u_fit<1, 3>(u_mul(zacc, ratio));
         u3_store<CU>(row(d), tx, ty, ratio);
       }
-      // ---- common denominator zeta = Z_16 ----
+      // ---- common denominator zeta = Z_TBL ----
       T lam = one, next = ratio;
       if constexpr (ISO) {
-        if constexpr (GLV) u3_store<CU>(row(16), tx, ty, u_fit<1, 3>(u_mul_k<CU>(tx, CU::BETA)));
+        if constexpr (GLV) u3_store<CU>(row(TBL), tx, ty, u_fit<1, 3>(u_mul_k<CU>(tx, CU::BETA)));
       } else {
         // 1 / zeta (zeta = 0 only for degenerate units, which are redone anyway: the inverse of 0 is 0)
         Fe<L> c;
@@ -356,9 +422,9 @@ __global__ void __launch_bounds__(WG, (coz_occupancy<CU, GLV>())) k_scalarmul_co
         lam = u_as<1, 3>(u_to_mont<CU>(c));
         const T l2 = u_fit<1, 3>(u_sqr(lam));
         const T l3 = u_fit<1, 3>(u_mul(l2, lam));
-        u3_store<CU>(row(16), u_fit<1, 3>(u_mul(tx, l2)), u_fit<1, 3>(u_mul(ty, l3)), one);
+        u3_store<CU>(row(TBL), u_fit<1, 3>(u_mul(tx, l2)), u_fit<1, 3>(u_mul(ty, l3)), one);
       }
-      for (int d = 15; d >= 1; --d) {
+      for (int d = TBL - 1; d >= 1; --d) {
         lam = u_fit<1, 3>(u_mul(lam, next));
         T x, y;
         u3_load<CU>(x, y, next, row(d));
@@ -376,89 +442,159 @@ __global__ void __launch_bounds__(WG, (coz_occupancy<CU, GLV>())) k_scalarmul_co
       }
     }
 
-    // ---- ladder: per window 5 doublings and one mixed addition (two with GLV) ----
-    constexpr int LAST_SUB = GLV ? 6 : 5;  // sub 0..4: doublings, 5: addition (6: second half's addition)
-    int win, sub;
-    {
-      // the top window's (first) addition has nothing to add to: the accumulator starts as that signed
-      // entry -- affine, so Z = 1 -- or at infinity for digit 0
-      uint32_t d;
-      bool neg;
-      booth(NWIN - 1, false, d, neg);
-      T tx, ty;
-      u2_load<CU>(tx, ty, row(d ? d : 1));
-      U<CU, 2, 4> sy;
-      u_select(sy, neg, u_neg(ty), u_as<2, 4>(ty));
-      q.x = tx;
-      q.y = u_reduce(sy);
-      q.z = u_as<UJac<CU>::ZK, UJac<CU>::ZV>(one);
-      if (d == 0) u_set_zero(q.z);
-      if constexpr (GLV) {
-        win = NWIN - 1;
-        sub = 6;  // the second half's addition of the top window comes next
-      } else {
-        win = NWIN - 2;
-        sub = 0;
+    // ---- ladder: per window WB doublings and one mixed addition (two with GLV) ----
+    if constexpr (CT) {
+      // secret scalars: a fixed schedule, every table row read at every lookup, selects only
+      constexpr int FULLW = coz_full_windows<CU, WB>();
+      auto lookup = [&](int w, T& ex, T& ey, uint32_t& d) {
+        bool neg;
+        booth_digit<WB, SB>(k, w, d, neg);
+        u_set_zero(ex);
+        u_set_zero(ey);
+#pragma unroll 2
+        for (int j = 1; j <= TBL; ++j) {
+          T cx, cy;
+          u2_load<CU>(cx, cy, row(j));
+          const uint64_t m = __builtin_amdgcn_uicmp(d, (uint32_t)j, 32 /* ICMP_EQ */);
+          u_cmov_ct(ex, m, cx);
+          u_cmov_ct(ey, m, cy);
+        }
+        U<CU, 2, 4> sy;
+        u_select_ct(sy, neg, u_neg(ey), u_as<2, 4>(ey));
+        ey = u_reduce(sy);
+      };
+      T zero;
+      u_set_zero(zero);
+      using TZ = U<CU, UJac<CU>::ZK, UJac<CU>::ZV>;
+      {
+        // the top window has nothing to add to: the accumulator starts as its signed entry (Z = 1), or at
+        // infinity for digit 0
+        T ex, ey;
+        uint32_t d;
+        lookup(NWIN - 1, ex, ey, d);
+        q.x = ex;
+        q.y = ey;
+        u_select_ct(q.z, d == 0, u_as<UJac<CU>::ZK, UJac<CU>::ZV>(zero), u_as<UJac<CU>::ZK, UJac<CU>::ZV>(one));
       }
-    }
-    bool fix_pending = false, fix_lane = false;
-    while (win >= 0) {
-      bool step_done;
-      if (fix_pending || sub < 5) {
-        UJac<CU> t;
-        ujac_dbl<CU>(t, q);
-        if (fix_pending) {
-          u_select(q.x, fix_lane, t.x, q.x);
-          u_select(q.y, fix_lane, t.y, q.y);
-          u_select(q.z, fix_lane, t.z, q.z);
-          fix_pending = false;
-          fix_lane = false;
-        } else {
+#pragma unroll 1
+      for (int win = NWIN - 2; win >= 0; --win) {
+#pragma unroll 1
+        for (int j = 0; j < WB; ++j) {
+          UJac<CU> t;
+          ujac_dbl<CU>(t, q);
           q = t;
         }
-        step_done = true;
-      } else {
-        const bool second = GLV && sub == 6;
-        uint32_t d;
-        bool neg;
-        booth(win, second, d, neg);
-        if (second) neg = !neg;  // [x^2]P = -sigma(P) = (beta x, -y)
         T ex, ey;
-        if constexpr (GLV) {
-          T eb;
-          u3_load<CU>(ex, ey, eb, row(d ? d : 1));
-          if (second) ex = eb;
-        } else {
-          u2_load<CU>(ex, ey, row(d ? d : 1));
-        }
+        uint32_t d;
+        lookup(win, ex, ey, d);
         const bool q_inf = u_limbs_all_zero(q.z);
-        const bool e_skip = (d == 0);
+        const bool e_skip = d == 0;
         UJac<CU> sum;
         bool hz, rz;
-        ujac_madd_signed<CU>(sum, hz, rz, q, ex, ey, neg);
-        const bool same_x = hz && !q_inf && !e_skip;
-        fix_lane = same_x && rz;  // q == entry: needs a doubling
-        if (same_x && !rz) u_set_zero(sum.z);  // q == -entry
-        if (__builtin_amdgcn_ballot_w64(q_inf) != 0) {  // accumulator at infinity: the sum is the entry
-          U<CU, 2, 4> sy;
-          u_select(sy, neg, u_neg(ey), u_as<2, 4>(ey));
-          u_select(sum.x, q_inf, ex, sum.x);
-          u_select(sum.y, q_inf, u_reduce(sy), sum.y);
-          u_select(sum.z, q_inf, u_as<UJac<CU>::ZK, UJac<CU>::ZV>(one), sum.z);
+        ujac_madd_ct<CU>(sum, hz, rz, q, ex, ey);
+        if (win < FULLW) {  // loop counter: the same for every lane and every scalar
+          T dx, dy, dz, sv, y8v;
+          ujac_dbl_affine<CU>(dx, dy, dz, sv, y8v, ex, ey);
+          const bool same_x = hz & !q_inf & !e_skip;
+          const uint64_t mt = ct_mask(same_x & rz);    // accumulator == entry
+          const uint64_t mc = ct_mask(same_x & !rz);   // accumulator == -entry
+          u_cmov_ct(sum.x, mt, dx);
+          u_cmov_ct(sum.y, mt, dy);
+          u_cmov_ct(sum.z, mt, TZ(u_as<UJac<CU>::ZK, UJac<CU>::ZV>(dz)));
+          u_cmov_ct(sum.z, mc, TZ(u_as<UJac<CU>::ZK, UJac<CU>::ZV>(zero)));
         }
-        const bool keep = e_skip || fix_lane;
-        u_select(q.x, keep, q.x, sum.x);
-        u_select(q.y, keep, q.y, sum.y);
-        u_select(q.z, keep, q.z, sum.z);
-        fix_pending = __builtin_amdgcn_ballot_w64(fix_lane) != 0;
-        step_done = !fix_pending;
+        const uint64_t mi = ct_mask(q_inf), mk = ct_mask(!e_skip);
+        u_cmov_ct(sum.x, mi, ex);  // accumulator at infinity: the sum is the entry
+        u_cmov_ct(sum.y, mi, ey);
+        u_cmov_ct(sum.z, mi, TZ(u_as<UJac<CU>::ZK, UJac<CU>::ZV>(one)));
+        u_cmov_ct(q.x, mk, sum.x);
+        u_cmov_ct(q.y, mk, sum.y);
+        u_cmov_ct(q.z, mk, sum.z);
       }
-      if (step_done) {
-        if (sub < LAST_SUB) {
-          ++sub;
+    } else {
+      constexpr int LAST_SUB = GLV ? WB + 1 : WB;  // sub 0..WB-1: doublings, WB: addition (WB+1: second half's addition)
+      int win, sub;
+      {
+        // the top window's (first) addition has nothing to add to: the accumulator starts as that signed
+        // entry -- affine, so Z = 1 -- or at infinity for digit 0
+        uint32_t d;
+        bool neg;
+        booth(NWIN - 1, false, d, neg);
+        T tx, ty;
+        u2_load<CU>(tx, ty, row(d ? d : 1));
+        U<CU, 2, 4> sy;
+        u_select(sy, neg, u_neg(ty), u_as<2, 4>(ty));
+        q.x = tx;
+        q.y = u_reduce(sy);
+        q.z = u_as<UJac<CU>::ZK, UJac<CU>::ZV>(one);
+        if (d == 0) u_set_zero(q.z);
+        if constexpr (GLV) {
+          win = NWIN - 1;
+          sub = WB + 1;  // the second half's addition of the top window comes next
         } else {
+          win = NWIN - 2;
           sub = 0;
-          --win;
+        }
+      }
+      bool fix_pending = false, fix_lane = false;
+      while (win >= 0) {
+        bool step_done;
+        if (fix_pending || sub < WB) {
+          UJac<CU> t;
+          ujac_dbl<CU>(t, q);
+          if (fix_pending) {
+            u_select(q.x, fix_lane, t.x, q.x);
+            u_select(q.y, fix_lane, t.y, q.y);
+            u_select(q.z, fix_lane, t.z, q.z);
+            fix_pending = false;
+            fix_lane = false;
+          } else {
+            q = t;
+          }
+          step_done = true;
+        } else {
+          const bool second = GLV && sub == WB + 1;
+          uint32_t d;
+          bool neg;
+          booth(win, second, d, neg);
+          if (second) neg = !neg;  // [x^2]P = -sigma(P) = (beta x, -y)
+          T ex, ey;
+          if constexpr (GLV) {
+            T eb;
+            u3_load<CU>(ex, ey, eb, row(d ? d : 1));
+            if (second) ex = eb;
+          } else {
+            u2_load<CU>(ex, ey, row(d ? d : 1));
+          }
+          const bool q_inf = u_limbs_all_zero(q.z);
+          const bool e_skip = (d == 0);
+          UJac<CU> sum;
+          bool hz, rz;
+          ujac_madd_signed<CU>(sum, hz, rz, q, ex, ey, neg);
+          const bool same_x = hz && !q_inf && !e_skip;
+          fix_lane = same_x && rz;  // q == entry: needs a doubling
+          if (same_x && !rz) u_set_zero(sum.z);  // q == -entry
+          if (__builtin_amdgcn_ballot_w64(q_inf) != 0) {  // accumulator at infinity: the sum is the entry
+            U<CU, 2, 4> sy;
+            u_select(sy, neg, u_neg(ey), u_as<2, 4>(ey));
+            u_select(sum.x, q_inf, ex, sum.x);
+            u_select(sum.y, q_inf, u_reduce(sy), sum.y);
+            u_select(sum.z, q_inf, u_as<UJac<CU>::ZK, UJac<CU>::ZV>(one), sum.z);
+          }
+          const bool keep = e_skip || fix_lane;
+          u_select(q.x, keep, q.x, sum.x);
+          u_select(q.y, keep, q.y, sum.y);
+          u_select(q.z, keep, q.z, sum.z);
+          fix_pending = __builtin_amdgcn_ballot_w64(fix_lane) != 0;
+          step_done = !fix_pending;
+        }
+        if (step_done) {
+          if (sub < LAST_SUB) {
+            ++sub;
+          } else {
+            sub = 0;
+            --win;
+          }
         }
       }
     }

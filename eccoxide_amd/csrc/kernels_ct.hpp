@@ -1,0 +1,341 @@
+// Secret-scalar kernels (ECCX_CT_SCAN) on the unsaturated field: fixed base.
+//
+// The reference's Point::mul_base is constant-time: select_from_table reads every entry of the
+// window's table and keeps one by masks (src/curve/projective.rs:427-434, :965-981;
+// src/curve/curve25519.rs:840-869).  These kernels keep that discipline -- no memory address and no
+// branch depends on a scalar digit -- on the fast field layer (ufe.hpp):
+//
+//   table     signed W-bit windows (Booth): entry (w, d) = d * 2^(W w) * G for d = 1 .. 2^(W-1), affine
+//             (Weierstrass: x, y; edwards25519: y - x, y + x, 2d x y), one contiguous slice per window.
+//             k*G does not depend on the window width: W = 6 gives 43 additions where the reference's
+//             4-bit comb makes 64.
+//   lookup    the window's slice is the same for every lane, so the WORKGROUP copies it into LDS once
+//             (double-buffered, one barrier per window) and every lane reads every entry from there by
+//             broadcast ds_read_b128 -- uniform addresses -- and keeps the entry of its own digit with
+//             v_cndmask.  The sign of the digit is applied by selects as well.
+//   addition  edwards25519: the complete 7-product addition (ued_add_niels), no special cases exist.
+//             Weierstrass: mixed addition in XYZZ coordinates (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2;
+//             madd-2008-s: 8 products + 2 squares -- a comb never doubles, so the Jacobian Z is never
+//             needed as such).  The formula is not complete; what it misses is handled by selects only:
+//               accumulator at infinity -> the entry;  digit 0 -> keep the accumulator;
+//               accumulator == -entry -> infinity;     accumulator == entry -> 2 * entry, computed from the
+//               entry's AFFINE coordinates (3 products + 3 squares, only in the windows named below).
+//             Windows are added LOW to HIGH, so before window w the accumulator is s*G with
+//             |s| < 2^(W w) * 2^(W-1) / (2^W - 1) and the entry is e*G with 2^(W w) <= |e| <= 2^(W w + W - 1):
+//             s = +-e (mod n) needs |s| + |e| >= n, impossible while W (w + 1) <= NBITS - 1 (n >= 2^(NBITS-1)).
+//             Only the top ct_unsafe_windows() windows run the two collision selects (for ANY scalar
+//             string, canonical or not); tests/test_ct_model.py checks the bound by enumeration on
+//             small parameters.
+//
+// Everything a lane does is the same instruction stream whatever its scalar; the only branches are loop
+// counters and the bounds of the batch.  tools/isa_histogram.py --branches lists them per kernel.
+#pragma once
+#include "kernels_unsat.hpp"
+
+namespace eccx {
+
+#ifndef ECCX_CT_BASE_BITS
+#define ECCX_CT_BASE_BITS 6
+#endif
+template <class CU>
+constexpr int ct_base_bits() { return ECCX_CT_BASE_BITS; }
+template <class CU>
+constexpr int ct_base_windows() { return (8 * CU::Sat::SB + 1 + ct_base_bits<CU>() - 1) / ct_base_bits<CU>(); }
+template <class CU>
+constexpr int ct_base_entries() { return 1 << (ct_base_bits<CU>() - 1); }
+// words per table entry, padded to 16 bytes: Weierstrass (x, y), edwards25519 (y - x, y + x, 2d x y)
+template <class CU>
+constexpr int ct_entry_words() { return (((CU::KIND == UK_PM19 ? 3 : 2) * CU::N + 3) / 4) * 4; }
+// windows (counted from the top) in which accumulator == +-entry is possible: those with W (w + 1) >= NBITS
+template <class CU>
+constexpr int ct_unsafe_windows() {
+  constexpr int W = ct_base_bits<CU>();
+  return ct_base_windows<CU>() - ((CU::Sat::NBITS + W - 1) / W) + 1;
+}
+
+// select_from_table over a slice held in LDS: every lane reads entries 1 .. ENT (uniform addresses)
+// and keeps entry d; out is untouched for d = 0 (or any d outside the slice)
+template <int EW, int ENT>
+ECCX_DEV void ct_scan_lds(uint32_t (&out)[EW], const uint4* __restrict__ slice, uint32_t d) {
+  static_assert(EW % 4 == 0, "entries are padded to 16 bytes");
+#pragma unroll 4
+  for (int j = 0; j < ENT; ++j) {
+    const uint64_t m = __builtin_amdgcn_uicmp(d, (uint32_t)(j + 1), 32 /* ICMP_EQ */);
+#pragma unroll
+    for (int c = 0; c < EW / 4; ++c) {
+      const uint4 v = slice[j * (EW / 4) + c];
+      ct_cmov4(out[4 * c], out[4 * c + 1], out[4 * c + 2], out[4 * c + 3], v.x, v.y, v.z, v.w, m);
+    }
+  }
+}
+
+// The workgroup's copy of one window slice, global -> registers (issued early) -> LDS (written late)
+template <int SLICE4>
+struct CtSliceStage {
+  static constexpr int PER = (SLICE4 + WG - 1) / WG;
+  uint4 r[PER];
+  ECCX_DEV void load(const uint4* __restrict__ src) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int at = i * WG + (int)threadIdx.x;
+      r[i] = src[at < SLICE4 ? at : SLICE4 - 1];  // clamped: uniform trip count, no out-of-bounds read
+    }
+  }
+  ECCX_DEV void store(uint4* __restrict__ dst) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int at = i * WG + (int)threadIdx.x;
+      if (at < SLICE4) dst[at] = r[i];
+    }
+  }
+};
+
+// ---- Weierstrass: XYZZ accumulator -------------------------------------------------------------------
+template <class CU>
+struct UXyzz {
+  U<CU, 1, 3> x, y, zz, zzz;  // infinity <=> every limb of zz is zero
+};
+
+// r = p + (x2, y2) (madd-2008-s); h_zero / r_zero: the two differences vanish (mod p) -- reported only,
+// the caller decides what a collision means.  WITH_TESTS = false skips the two comparisons.
+template <class CU, bool WITH_TESTS>
+ECCX_DEV void uxyzz_madd(UXyzz<CU>& r, bool& h_zero, bool& r_zero, const UXyzz<CU>& p, const U<CU, 1, 3>& x2,
+                         const U<CU, 1, 3>& y2) {
+  auto u2 = u_mul(x2, p.zz);
+  auto s2 = u_mul(y2, p.zzz);
+  auto h = u_reduce(u_sub(u2, p.x));   // P
+  auto rr = u_reduce(u_sub(s2, p.y));  // R
+  if constexpr (WITH_TESTS) {
+    h_zero = u_is_zero_mod_p_ct(h);
+    r_zero = u_is_zero_mod_p_ct(rr);
+  } else {
+    h_zero = false;
+    r_zero = false;
+  }
+  auto hh = u_sqr(h);          // PP
+  auto hhh = u_mul(h, hh);     // PPP
+  auto v = u_mul(p.x, hh);     // Q
+  auto r2 = u_sqr(rr);
+  auto x3 = u_reduce(u_sub(u_sub(u_sub(r2, hhh), v), v));
+  r.x = x3;
+  if constexpr (CU::KIND == UK_MONT) {
+    r.y = u_fit<1, 3>(u_mul_add(rr, u_sub(v, x3), u_neg(p.y), hhh));  // one reduction for both products
+  } else if constexpr (UB<CU>::SPARSE) {
+    r.y = u_mul_sub(rr, u_sub(v, x3), p.y, hhh);
+  } else {
+    auto y3a = u_mul(rr, u_sub(v, x3));
+    auto y1h = u_mul(p.y, hhh);
+    r.y = u_reduce(u_sub(y3a, y1h));
+  }
+  r.zz = u_fit<1, 3>(u_mul(p.zz, hh));
+  r.zzz = u_fit<1, 3>(u_mul(p.zzz, hhh));
+}
+
+// r = 2 * (x, y) from affine coordinates (mdbl-2008-s-1): 3 products + 3 squares
+template <class CU>
+ECCX_DEV void uxyzz_dbl_affine(UXyzz<CU>& r, const U<CU, 1, 3>& x, const U<CU, 1, 3>& y) {
+  auto u = u_reduce(u_add(y, y));   // 2 y
+  auto v = u_sqr(u);                // ZZ3
+  auto w = u_mul(u, v);             // ZZZ3
+  auto s = u_mul(x, v);
+  auto xx = u_sqr(x);
+  U<CU, 1, 3> m;
+  if constexpr (CU::Sat::A0) {
+    m = u_reduce(u_add(u_add(xx, xx), xx));  // 3 x^2
+  } else {
+    U<CU, 1, 2> one;
+#pragma unroll
+    for (int i = 0; i < CU::N; ++i) one.v[i] = CU::ONE[i];
+    const auto xm = u_sub(xx, one);          // a = -3: 3 (x^2 - 1)
+    m = u_reduce(u_add(u_add(xm, xm), xm));
+  }
+  auto x3 = u_reduce(u_sub(u_sub(u_sqr(m), s), s));
+  auto y3a = u_mul(m, u_sub(s, x3));
+  auto wy = u_mul(w, y);
+  r.x = x3;
+  r.y = u_reduce(u_sub(y3a, wy));
+  r.zz = u_fit<1, 3>(v);
+  r.zzz = u_fit<1, 3>(w);
+}
+
+// affine points as canonical big-endian bytes x | y -> table entries (x, y) in the field's working form,
+// `stride` words per entry (the padding words are zeroed); a zero record (the engine's encoding of
+// infinity: the entry of a digit that cannot occur) stays zero
+template <class CU>
+__global__ void k_affine_to_cttable(size_t entries, const uint8_t* __restrict__ affine, uint32_t* __restrict__ table,
+                                    int stride) {
+  using CS = typename CU::Sat;
+  constexpr int L = CS::L;
+  constexpr int FB = CS::FB;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= entries) return;
+  Fe<L> px, py;
+  fe_load_be<CS>(px, affine + i * (size_t)(2 * FB));
+  fe_load_be<CS>(py, affine + i * (size_t)(2 * FB) + FB);
+  const auto ux = u_to_mont<CU>(px);
+  const auto uy = u_to_mont<CU>(py);
+  uint32_t* o = table + i * (size_t)stride;
+  for (int k = 0; k < stride; ++k) o[k] = k < CU::N ? ux.v[k] : (k < 2 * CU::N ? uy.v[k - CU::N] : 0u);
+}
+
+// Fixed base, secret scalars (Point::mul_base, src/curve/fiat/curve_macros.rs:55-63 ->
+// mul_base_table_{am3,a0}, projective.rs:945-981).  table: ct_base_windows() slices of ct_base_entries()
+// entries of ct_entry_words() words; rows (X ZZ, Y ZZZ, ZZ) are Jacobian rows for
+// k_batch_to_affine_unsat<NORM_JACOBIAN>.
+template <class CU>
+__global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_base_ct(size_t n, const uint8_t* __restrict__ scalars,
+                                                                               const uint32_t* __restrict__ table,
+                                                                               uint32_t* __restrict__ rows_out,
+                                                                               uint8_t* __restrict__ flags) {
+  using CS = typename CU::Sat;
+  constexpr int N = CU::N;
+  constexpr int SB = CS::SB;
+  constexpr int W = ct_base_bits<CU>();
+  constexpr int NWIN = ct_base_windows<CU>();
+  constexpr int ENT = ct_base_entries<CU>();
+  constexpr int EW = ct_entry_words<CU>();
+  constexpr int SLICE4 = ENT * EW / 4;
+  constexpr int UNSAFE = ct_unsafe_windows<CU>();
+  static_assert(UNSAFE >= 1 && UNSAFE <= NWIN, "window bookkeeping");
+  using T = U<CU, 1, 3>;
+  __shared__ uint4 lds[2][SLICE4];
+  const uint4* __restrict__ gtab = reinterpret_cast<const uint4*>(table);
+  T one;
+#pragma unroll
+  for (int i = 0; i < N; ++i) one.v[i] = CU::ONE[i];
+  for (size_t base = (size_t)blockIdx.x * WG; base < n; base += (size_t)gridDim.x * WG) {
+    const size_t gid = base + threadIdx.x;
+    const bool active = gid < n;
+    const size_t idx = active ? gid : n - 1;
+    const uint8_t* __restrict__ k = scalars + idx * (size_t)SB;
+    CtSliceStage<SLICE4> stage;
+    stage.load(gtab);
+    __syncthreads();  // the previous batch's last reads of buffer 0 are done
+    stage.store(lds[0]);
+    __syncthreads();
+    UXyzz<CU> q;
+    q.x = one;
+    q.y = one;
+    u_set_zero(q.zz);
+    u_set_zero(q.zzz);
+    for (int w = 0; w < NWIN; ++w) {
+      if (w + 1 < NWIN) stage.load(gtab + (size_t)(w + 1) * SLICE4);
+      uint32_t d;
+      bool neg;
+      booth_digit<W, SB>(k, w, d, neg);
+      uint32_t ew[EW];
+#pragma unroll
+      for (int i = 0; i < EW; ++i) ew[i] = 0;
+      ct_scan_lds<EW, ENT>(ew, lds[w & 1], d);
+      T x2, y2;
+#pragma unroll
+      for (int i = 0; i < N; ++i) { x2.v[i] = ew[i]; y2.v[i] = ew[N + i]; }
+      {
+        U<CU, 2, 4> sy;
+        u_select_ct(sy, neg, u_neg(y2), u_as<2, 4>(y2));
+        y2 = u_reduce(sy);
+      }
+      const bool q_inf = u_limbs_all_zero(q.zz);
+      const bool skip = d == 0;
+      UXyzz<CU> sum;
+      if (w >= NWIN - UNSAFE) {  // loop counter: the same for every lane and every scalar
+        bool hz, rz;
+        uxyzz_madd<CU, true>(sum, hz, rz, q, x2, y2);
+        UXyzz<CU> dbl;
+        uxyzz_dbl_affine<CU>(dbl, x2, y2);
+        const bool same_x = hz & !q_inf & !skip;
+        const bool twice = same_x & rz;    // accumulator == entry
+        const bool cancel = same_x & !rz;  // accumulator == -entry
+        const uint64_t mt = ct_mask(twice), mc = ct_mask(cancel);
+        u_cmov_ct(sum.x, mt, dbl.x);
+        u_cmov_ct(sum.y, mt, dbl.y);
+        u_cmov_ct(sum.zz, mt, dbl.zz);
+        u_cmov_ct(sum.zzz, mt, dbl.zzz);
+        T zero;
+        u_set_zero(zero);
+        u_cmov_ct(sum.zz, mc, zero);
+        u_cmov_ct(sum.zzz, mc, zero);
+      } else {
+        bool hz, rz;
+        uxyzz_madd<CU, false>(sum, hz, rz, q, x2, y2);
+      }
+      // accumulator at infinity: the sum is the entry itself
+      const uint64_t mi = ct_mask(q_inf), mk = ct_mask(!skip);
+      u_cmov_ct(sum.x, mi, x2);
+      u_cmov_ct(sum.y, mi, y2);
+      u_cmov_ct(sum.zz, mi, one);
+      u_cmov_ct(sum.zzz, mi, one);
+      u_cmov_ct(q.x, mk, sum.x);
+      u_cmov_ct(q.y, mk, sum.y);
+      u_cmov_ct(q.zz, mk, sum.zz);
+      u_cmov_ct(q.zzz, mk, sum.zzz);
+      if (w + 1 < NWIN) stage.store(lds[(w + 1) & 1]);
+      __syncthreads();
+    }
+    if (active) {
+      // (X, Y, ZZ, ZZZ) -> the Jacobian triple (X ZZ : Y ZZZ : ZZ): X ZZ / ZZ^2 = x, Y ZZZ / ZZ^3 = Y / ZZZ = y
+      u3_store<CU>(rows_out + idx * (size_t)urow3_words<CU>(), u_fit<1, 3>(u_mul(q.x, q.zz)), u_fit<1, 3>(u_mul(q.y, q.zzz)), q.zz);
+      flags[idx] = 0;
+    }
+  }
+}
+
+// ---- edwards25519 fixed base, secret scalars (curve25519.rs:840-869) -----------------------------------
+// Complete additions: digit 0 adds the neutral element (1, 1, 0), which is what the scan leaves when no
+// entry matches; a negative digit swaps y - x with y + x and negates 2d x y.
+template <class CU>
+__global__ void __launch_bounds__(WG, 4) k_ed_scalarmul_base_ct(size_t n, const uint8_t* __restrict__ scalars,
+                                                                const uint32_t* __restrict__ table,
+                                                                uint32_t* __restrict__ rows_out, uint8_t* __restrict__ flags) {
+  constexpr int N = CU::N;
+  constexpr int W = ct_base_bits<CU>();
+  constexpr int NWIN = ct_base_windows<CU>();
+  constexpr int ENT = ct_base_entries<CU>();
+  constexpr int EW = ct_entry_words<CU>();
+  constexpr int SLICE4 = ENT * EW / 4;
+  using T = U<CU, 1, 3>;
+  __shared__ uint4 lds[2][SLICE4];
+  const uint4* __restrict__ gtab = reinterpret_cast<const uint4*>(table);
+  for (size_t base = (size_t)blockIdx.x * WG; base < n; base += (size_t)gridDim.x * WG) {
+    const size_t gid = base + threadIdx.x;
+    const bool active = gid < n;
+    const size_t idx = active ? gid : n - 1;
+    const uint8_t* __restrict__ k = scalars + idx * 32;
+    CtSliceStage<SLICE4> stage;
+    stage.load(gtab);
+    __syncthreads();
+    stage.store(lds[0]);
+    __syncthreads();
+    T qx, qy, qz, qt;  // the neutral element (0, 1, 1, 0)
+    u_set_zero(qx); u_set_zero(qy); u_set_zero(qz); u_set_zero(qt);
+    qy.v[0] = 1; qz.v[0] = 1;
+    for (int w = 0; w < NWIN; ++w) {
+      if (w + 1 < NWIN) stage.load(gtab + (size_t)(w + 1) * SLICE4);
+      uint32_t d;
+      bool neg;
+      booth_digit<W, 32>(k, w, d, neg);
+      uint32_t ew[EW];
+#pragma unroll
+      for (int i = 0; i < EW; ++i) ew[i] = 0;
+      ew[0] = 1;  // y - x
+      ew[N] = 1;  // y + x
+      ct_scan_lds<EW, ENT>(ew, lds[w & 1], d);
+      T a, b, t2d, ym, yp;
+#pragma unroll
+      for (int i = 0; i < N; ++i) { a.v[i] = ew[i]; b.v[i] = ew[N + i]; t2d.v[i] = ew[2 * N + i]; }
+      u_select_ct(ym, neg, b, a);
+      u_select_ct(yp, neg, a, b);
+      U<CU, 2, 4> t2;
+      u_select_ct(t2, neg, u_neg(t2d), u_as<2, 4>(t2d));
+      ued_add_niels<CU, 2, 4>(qx, qy, qz, qt, ym, yp, t2);
+      if (w + 1 < NWIN) stage.store(lds[(w + 1) & 1]);
+      __syncthreads();
+    }
+    if (active) {
+      u3_store<CU>(rows_out + idx * (size_t)urow3_words<CU>(), qx, qy, qz);
+      flags[idx] = 0;
+    }
+  }
+}
+
+}  // namespace eccx

@@ -272,6 +272,23 @@ ECCX_DEV uint32_t comb_digit(const uint8_t* __restrict__ k, int w) {
   if (b + 2 < SB) v |= (uint32_t)k[SB - 3 - b] << 16;
   return (v >> (pos & 7)) & ((1u << W) - 1u);
 }
+// Booth digit of window w of the big-endian SB-byte scalar k, W-bit windows: value d_w in
+// [-2^(W-1), 2^(W-1)] with sum d_w 2^(W w) = k, returned as magnitude and sign.  Which bytes are read
+// depends on w only.
+template <int W, int SB>
+ECCX_DEV void booth_digit(const uint8_t* __restrict__ k, int w, uint32_t& d, bool& neg) {
+  static_assert(W >= 2 && W <= 8, "a window and its borrow bit must fit two bytes at any bit offset");
+  const int pos = W * w - 1 + 8;  // bit position of the borrow bit, counted from one byte below the scalar
+  const int bi = pos >> 3;
+  const uint32_t b0 = (bi >= 1 && bi <= SB) ? k[SB - bi] : 0u;
+  const uint32_t b1 = (bi + 1 <= SB) ? k[SB - bi - 1] : 0u;
+  const uint32_t wv = ((b0 | (b1 << 8)) >> (pos & 7)) & ((1u << (W + 1)) - 1u);
+  const uint32_t s = ~((wv >> W) - 1u);  // all ones for a negative digit
+  const uint32_t m = (((1u << (W + 1)) - wv - 1u) & s) | (wv & ~s);
+  d = (m >> 1) + (m & 1u);
+  neg = (s & 1u) != 0;
+}
+
 template <class CU, bool FROM_INFINITY = false>
 ECCX_DEV void ucomb_accumulate(UJac<CU>& q, const uint8_t* __restrict__ k, const uint32_t* __restrict__ table);
 
@@ -301,7 +318,7 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_var_uns
     const size_t idx = active ? gid : n - 1;
     if (opts & OPT_ONLY_MARKED) {
       // fix-up pass behind the affine-table ladder (kernels_coz.hpp): only the units it marked are redone
-      active = active && flags[idx] == 0xFE;
+      active = active && flags[idx] == FLAG_REDO;
       if (__builtin_amdgcn_ballot_w64(active) == 0) continue;
     }
 
@@ -1137,8 +1154,13 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_var_mir
   auto row = [&](uint32_t e) { return slab + (size_t)e * WG * W; };
   for (size_t base = (size_t)blockIdx.x * WG; base < n; base += (size_t)gridDim.x * WG) {
     const size_t gid = base + threadIdx.x;
-    const bool active = gid < n;
+    bool active = gid < n;
     const size_t idx = active ? gid : n - 1;
+    if (opts & OPT_ONLY_MARKED) {
+      // behind the secret-scalar affine-table ladder: only the units it marked (from the base point alone)
+      active = active && flags[idx] == FLAG_REDO;
+      if (__builtin_amdgcn_ballot_w64(active) == 0) continue;
+    }
     U<CU, 1, 3> one, zero;
     u_set_zero(zero);
 #pragma unroll
@@ -1397,7 +1419,9 @@ __global__ void __launch_bounds__(WG) k_batch_to_affine_unsat(size_t n, const ui
     // fed a point that is not on the curve (rejected under ECCX_VALIDATE_POINTS, or garbage
     // without it) can arrive with Z = p or 2p -- e.g. an Edwards "point" with x = +-y doubles to
     // Z = 0 -- and must not zero the shared inverse of the units normalised beside it
-    auto z_present = [&](const T& z) { return !u_is_zero_mod_p(u_reduce(z)); };
+    // (decided without a data-dependent branch: the presence test and every substitution below are selects,
+    // as z_inverse_ct / to_affine_ct are in the reference, src/curve/projective.rs:655-682)
+    auto z_present = [&](const T& z) { return !u_is_zero_mod_p_ct(u_reduce(z)); };
     T pre[UN];  // prefix products of the (substituted) Z values
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
@@ -1405,7 +1429,7 @@ __global__ void __launch_bounds__(WG) k_batch_to_affine_unsat(size_t n, const ui
       T x, y, z = one;
       if (i < n) {
         u3_load<CU>(x, y, z, rows + i * (size_t)W3);
-        if (!z_present(z)) z = one;  // z_inverse_ct substitutes 1 (projective.rs:655-659)
+        u_select(z, z_present(z), z, one);  // z_inverse_ct substitutes 1 (projective.rs:655-659)
       }
       if (u == 0) pre[0] = z;
       else pre[u] = u_fit<1, 3>(u_mul(pre[u - 1], z));
@@ -1425,7 +1449,7 @@ __global__ void __launch_bounds__(WG) k_batch_to_affine_unsat(size_t n, const ui
       if (i < n) {
         u3_load<CU>(x, y, z, rows + i * (size_t)W3);
         present = z_present(z);
-        if (!present) z = one;
+        u_select(z, present, z, one);
       }
       T zi;
       if (u > 0) {
@@ -1444,22 +1468,26 @@ __global__ void __launch_bounds__(WG) k_batch_to_affine_unsat(size_t n, const ui
         if constexpr (MODE == NORM_EDWARDS || MODE == NORM_HOMOGENEOUS) u_to_canonical<CU>(ay, u_mul(y, zi));
       }
       if (i < n) {
-        const bool rejected = flags[i] == 2;
+        const uint8_t fl = flags[i];
+        const bool rejected = fl == 2;
         if constexpr (MODE == NORM_MONTGOMERY_U) {
-          if (!present) fe_zero<CS>(ax);
+#pragma unroll
+          for (int k = 0; k < L; ++k) ax.v[k] = present ? ax.v[k] : 0u;
           fe_store_le<CS>(out + i * (size_t)FB, ax);
           flags[i] = fe_is_zero<CS>(ax) ? 1 : 0;
         } else if constexpr (MODE == NORM_EDWARDS) {
           bool neutral = fe_is_zero<CS>(ax);
 #pragma unroll
-          for (int k = 0; k < L; ++k) neutral = neutral && (ay.v[k] == (k == 0 ? 1u : 0u));
-          if (rejected) { fe_zero<CS>(ax); fe_zero<CS>(ay); }
+          for (int k = 0; k < L; ++k) neutral = neutral & (ay.v[k] == (k == 0 ? 1u : 0u));
+#pragma unroll
+          for (int k = 0; k < L; ++k) { ax.v[k] = rejected ? 0u : ax.v[k]; ay.v[k] = rejected ? 0u : ay.v[k]; }
           fe_store_le<CS>(out + i * (size_t)(2 * FB), ax);
           fe_store_le<CS>(out + i * (size_t)(2 * FB) + FB, ay);
           flags[i] = rejected ? 2 : (neutral ? 1 : 0);
-        } else {
-          const bool ok = present && !rejected;
-          if (!ok) { fe_zero<CS>(ax); fe_zero<CS>(ay); }
+        } else if (fl != FLAG_REDO) {  // a unit marked from its BASE POINT is redone by the kernel launched behind
+          const bool ok = present & !rejected;
+#pragma unroll
+          for (int k = 0; k < L; ++k) { ax.v[k] = ok ? ax.v[k] : 0u; ay.v[k] = ok ? ay.v[k] : 0u; }
           fe_store_be<CS>(out + i * (size_t)(2 * FB), ax);
           fe_store_be<CS>(out + i * (size_t)(2 * FB) + FB, ay);
           flags[i] = rejected ? 2 : (present ? 0 : 1);

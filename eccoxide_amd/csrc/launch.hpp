@@ -95,6 +95,21 @@ struct CurveOps {
                               uint32_t* scratch, uint32_t opts, const uint8_t* u1, const uint32_t* utable);
   int (*var_coz_fused_grid)(int cus, size_t n);
   hipError_t (*subgroup_check)(int grid, hipStream_t s, size_t n, uint8_t* xy, uint8_t* flags);
+  // Secret scalars (ECCX_CT_SCAN, kernels_ct.hpp / kernels_coz.hpp): no address and no branch depends on a
+  // scalar digit.
+  //   base_ct   fixed base over a table of ct_windows slices x ct_entries entries x ct_entry_words words, entry
+  //             (w, d) = d * 2^(ct_bits * w) * G for d = 1 .. ct_entries, made by ct_convert from affine bytes;
+  //             rows for to_affine_var
+  //   var_ct    variable base, Weierstrass (null for edwards25519): the affine-table ladder with every table
+  //             row read at every lookup; slab rows of coz_row_words; rows for to_affine_var; units marked
+  //             0xFE (from the base point alone) are redone by `var` with the scan and only-marked options
+  int ct_bits, ct_windows, ct_entries, ct_entry_words;
+  hipError_t (*ct_convert)(hipStream_t s, size_t entries, const uint8_t* affine, uint32_t* table);
+  hipError_t (*base_ct)(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint32_t* table, uint32_t* rows,
+                        uint8_t* flags);
+  hipError_t (*var_ct)(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint8_t* points, uint32_t* rows,
+                       uint8_t* flags, uint32_t* scratch, uint32_t opts);
+  int (*var_ct_grid)(int cus, size_t n);
 };
 // units normalised per lane with one inversion: 16 where the prefix products fit the register
 // file (8-limb fields), 8 above

@@ -771,6 +771,59 @@ ECCX_DEV bool u_is_zero_mod_p(const U<C, 1, 3>& a) {
   return d0 == 0 || d1 == 0 || d2 == 0;
 }
 
+// value == 0 (mod p) for the output of u_reduce, without the early exit of u_is_zero_mod_p
+template <class C>
+ECCX_DEV bool u_is_zero_mod_p_ct(const U<C, 1, 3>& a) {
+  uint32_t d0 = 0, d1 = 0, d2 = 0;
+#pragma unroll
+  for (int i = 0; i < C::N; ++i) {
+    d0 |= a.v[i];
+    d1 |= a.v[i] ^ C::P[i];
+    d2 |= a.v[i] ^ C::P2[i];
+  }
+  return (d0 == 0) | (d1 == 0) | (d2 == 0);
+}
+
+// ---- selects the compiler cannot turn into control flow (secret-scalar kernels) -----------------------
+// hipcc is free to compile `take ? a : b` as an EXEC-masked region with an s_cbranch_execz around whatever
+// feeds it (it does: a table scan written with ?: came out with its LDS reads inside such regions, skipped
+// when no lane of the wave takes the entry -- a branch on scalar digits).  These forms are opaque: the lane
+// mask goes to VCC and the data through v_cndmask_b32 inside one asm volatile statement, so both operands
+// are always computed, every load that feeds them is always issued, and nothing is skipped.
+ECCX_DEV uint64_t ct_mask(bool take) { return __builtin_amdgcn_uicmp((uint32_t)take, 1u, 32 /* ICMP_EQ */); }
+// o[i] = lane in m ? a[i] : o[i], four words
+ECCX_DEV void ct_cmov4(uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3, uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3,
+                       uint64_t m) {
+  asm volatile(
+      "s_mov_b64 vcc, %8\n\t"
+      "v_cndmask_b32_e32 %0, %0, %4, vcc\n\t"
+      "v_cndmask_b32_e32 %1, %1, %5, vcc\n\t"
+      "v_cndmask_b32_e32 %2, %2, %6, vcc\n\t"
+      "v_cndmask_b32_e32 %3, %3, %7, vcc"
+      : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3)
+      : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "s"(m)
+      : "vcc");
+}
+ECCX_DEV void ct_cmov1(uint32_t& o, uint32_t a, uint64_t m) {
+  asm volatile("s_mov_b64 vcc, %2\n\tv_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(o) : "v"(a), "s"(m) : "vcc");
+}
+// r = take ? a : r
+template <class C, int K, int V>
+ECCX_DEV void u_cmov_ct(U<C, K, V>& r, uint64_t m, const U<C, K, V>& a) {
+  constexpr int N = C::N;
+#pragma unroll
+  for (int i = 0; i + 4 <= N; i += 4) ct_cmov4(r.v[i], r.v[i + 1], r.v[i + 2], r.v[i + 3], a.v[i], a.v[i + 1], a.v[i + 2], a.v[i + 3], m);
+#pragma unroll
+  for (int i = N - N % 4; i < N; ++i) ct_cmov1(r.v[i], a.v[i], m);
+}
+// r = take_a ? a : b
+template <class C, int K, int V>
+ECCX_DEV void u_select_ct(U<C, K, V>& r, bool take_a, const U<C, K, V>& a, const U<C, K, V>& b) {
+  U<C, K, V> t = b;
+  u_cmov_ct(t, ct_mask(take_a), a);
+  r = t;
+}
+
 // ---- conversions with the saturated representation (plain integers, L x 32) --------------
 // plain saturated integer -> tight digits (value unchanged; below 2p for canonical input)
 template <class C>

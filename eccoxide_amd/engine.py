@@ -23,7 +23,7 @@ CHECK_SUBGROUP = 1 << 6
 UNCOMPRESSED = 1 << 7
 CT_SCAN = 1 << 8
 ASSUME_SUBGROUP = 1 << 9
-PREP_VAR, PREP_BASE, PREP_BASE_LDS, PREP_MIRROR = 1, 2, 4, 8
+PREP_VAR, PREP_BASE, PREP_BASE_LDS, PREP_MIRROR, PREP_CT = 1, 2, 4, 8, 16
 FLAG_FINITE, FLAG_INFINITY, FLAG_REJECTED = 0, 1, 2
 
 
@@ -115,15 +115,19 @@ class Engine:
         return t.numel() // width
 
     # ---- one-time costs ------------------------------------------------------
-    def prepare(self, curve, *, base: bool = True, base_lds: bool = False):
-        """eccx_prepare: build the fixed-base tables of `curve` now (blocking)."""
+    def prepare(self, curve, *, base: bool = True, base_lds: bool = False, ct: bool = False):
+        """eccx_prepare: build the fixed-base tables of `curve` now (blocking); ct: the signed-window table
+        of the secret-scalar (ECCX_CT_SCAN) fixed-base kernel."""
         self._check(self._lib.eccx_prepare(self._ctx, curve_id(curve),
-                                           (PREP_BASE if base else 0) | (PREP_BASE_LDS if base_lds else 0)))
+                                           (PREP_BASE if base else 0) | (PREP_BASE_LDS if base_lds else 0)
+                                           | (PREP_CT if ct else 0)))
 
-    def reserve(self, curve, max_n: int, *, var: bool = True, mirror: bool = False):
-        """eccx_reserve: size the scratch slab and row buffer for batches of up to max_n units."""
+    def reserve(self, curve, max_n: int, *, var: bool = True, mirror: bool = False, ct: bool = False):
+        """eccx_reserve: size the scratch slab and row buffer for batches of up to max_n units; ct: for the
+        secret-scalar (ECCX_CT_SCAN) variable-base ladder."""
         self._check(self._lib.eccx_reserve(self._ctx, curve_id(curve), int(max_n),
-                                           (PREP_VAR if var else 0) | (PREP_MIRROR if mirror else 0)))
+                                           (PREP_VAR if var else 0) | (PREP_MIRROR if mirror else 0)
+                                           | (PREP_CT if ct else 0)))
 
     def device_bytes(self) -> int:
         return int(self._lib.eccx_device_bytes(self._ctx))

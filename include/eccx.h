@@ -142,7 +142,10 @@ enum {
   ECCX_PREP_VAR = 1u << 0,      /* variable base and double-scalar, default kernels: window-table slab */
   ECCX_PREP_BASE = 1u << 1,     /* fixed base and double-scalar: the comb tables of the curve */
   ECCX_PREP_BASE_LDS = 1u << 2, /* ECCX_TABLE_IN_LDS image (edwards25519) */
-  ECCX_PREP_MIRROR = 1u << 3    /* ECCX_MIRROR_REFERENCE / ECCX_CT_SCAN / proj: slab of the mirror ladder */
+  ECCX_PREP_MIRROR = 1u << 3,   /* ECCX_MIRROR_REFERENCE / proj: slab of the mirror ladder */
+  ECCX_PREP_CT = 1u << 4        /* ECCX_CT_SCAN: eccx_prepare builds the signed-window table of the secret-scalar
+                                   fixed-base kernel (99-460 KB); eccx_reserve sizes the slabs of the scanning
+                                   variable-base ladder and of its fix-up pass */
 };
 
 /* flag values written per unit */

@@ -44,6 +44,7 @@ pub const ECCX_PREP_VAR: u32 = 1 << 0;
 pub const ECCX_PREP_BASE: u32 = 1 << 1;
 pub const ECCX_PREP_BASE_LDS: u32 = 1 << 2;
 pub const ECCX_PREP_MIRROR: u32 = 1 << 3;
+pub const ECCX_PREP_CT: u32 = 1 << 4; // ECCX_CT_SCAN: the secret-scalar fixed-base table / variable-base slabs
 
 // per-unit flags
 pub const ECCX_FLAG_FINITE: u8 = 0;

@@ -1,0 +1,101 @@
+"""CPU checks of the window bounds the secret-scalar kernels rely on (tests/ct_model.py).
+
+Exhaustive on small parameters: for every scalar of SB bytes, every collision accumulator == +-entry
+falls inside the windows that carry the collision selects -- ct_unsafe_windows() for the fixed-base
+comb (kernels_ct.hpp), coz_full_windows() for the variable-base ladder on a point of prime order
+(kernels_coz.hpp).  And on the real curves: the constructed collision scalars exist (so the GPU tests
+have something to bite on) and respect the same bounds.
+"""
+import json
+import os
+
+import pytest
+
+from tests import ct_model as M
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PRIMES = [257, 263, 509, 521, 1021, 2039, 4093, 8191, 16381, 32749, 65521, 61, 127]
+
+
+@pytest.mark.parametrize("w", [2, 3, 4, 5, 6])
+def test_booth_digits_reconstruct_the_scalar(w):
+    for k in list(range(0, 65536, 7)) + [65535, 65534, 32768]:
+        ds = M.booth_digits(k, 2, w)
+        assert all(abs(d) <= 1 << (w - 1) for d in ds)
+
+
+@pytest.mark.parametrize("w", [2, 3, 4, 5, 6])
+@pytest.mark.parametrize("n", PRIMES)
+def test_fixed_base_collisions_stay_in_the_unsafe_windows(w, n):
+    sb = 2
+    if n <= 1 << w:  # the model needs entries d G distinct from each other and from infinity
+        pytest.skip("order below the window's digit range")
+    nwin = (8 * sb + 1 + w - 1) // w
+    unsafe = M.fixed_base_unsafe_windows(sb, w, n.bit_length())
+    assert 1 <= unsafe <= nwin
+    hits = 0
+    for k in range(1 << (8 * sb)):
+        for win, _ in M.fixed_base_events(k, sb, w, n):
+            assert win >= nwin - unsafe, (k, win, nwin, unsafe)
+            hits += 1
+    # the bound is not vacuous: collisions do occur for orders that are small against 2^(8 SB)
+    if n.bit_length() <= 8 * sb - 2:
+        assert hits > 0
+
+
+@pytest.mark.parametrize("wb", [3, 4, 5])
+@pytest.mark.parametrize("n", PRIMES)
+def test_var_base_collisions_stay_in_the_full_windows(wb, n):
+    sb = 2
+    if n <= 1 << wb:
+        pytest.skip("order below the table's range")
+    full = M.var_base_full_windows(sb, wb, n.bit_length())
+    hits = 0
+    for k in range(1 << (8 * sb)):
+        for win, _ in M.var_base_events(k, sb, wb, n):
+            assert win < full, (k, win, full)
+            hits += 1
+    assert hits > 0  # k = n + 2 d always exists for n < 2^(8 SB) - 32
+
+
+CURVES = {"p256r1": (32, 256), "p384r1": (48, 384), "p521r1": (66, 521), "bls12_381_g1": (32, 255)}
+
+
+@pytest.mark.parametrize("curve", sorted(CURVES))
+def test_real_curve_collision_scalars(curve):
+    sb, nbits = CURVES[curve]
+    n = int(json.load(open(os.path.join(ROOT, "tests", "golden", "params.json")))[curve]["order"], 16)
+    assert n.bit_length() == nbits
+    w = 6
+    nwin = (8 * sb + 1 + w - 1) // w
+    unsafe = M.fixed_base_unsafe_windows(sb, w, nbits)
+    for k, ev in M.collision_scalars_fixed_base(sb, w, n, limit=16).items():
+        assert all(win >= nwin - unsafe for win, _ in ev), (hex(k), ev)
+    for wb in (4, 5):
+        full = M.var_base_full_windows(sb, wb, nbits)
+        found = M.collision_scalars_var_base(sb, wb, n, limit=16)
+        assert found, "k = n + 2 d must collide in the last window"
+        for k, ev in found.items():
+            assert all(win < full for win, _ in ev), (hex(k), ev)
+
+
+@pytest.mark.parametrize("sb,w", [(32, 6), (48, 6), (66, 6), (32, 5), (32, 7), (48, 5), (66, 4)])
+def test_every_reachable_digit_has_a_table_scalar(sb, w):
+    """The secret-scalar comb's table is built from SB-byte scalars d 2^(w i) (ensure_comb_ct, eccx_api.cpp): every
+    digit the recoding can produce must name a scalar below 2^(8 SB) -- except the single entry 2^(8 SB) itself
+    (the top window's digit 2^(8 SB - w i_top); a scalar of all ones recodes to it), which the build makes by a
+    doubling of 2^(8 SB - 1) G."""
+    top = 1 << (8 * sb)
+    nwin = (8 * sb + 1 + w - 1) // w
+    shift = 8 * sb - w * (nwin - 1)
+    assert 0 <= shift < w
+    seen_special = False
+    for k in (top - 1, top - 2, top >> 1, (top >> 1) - 1, (top >> 1) + 1, 1, 0, int("f" * (2 * sb - 1), 16)) + tuple(
+            (top - 1) ^ (1 << j) for j in range(0, 8 * sb, 5)):
+        for i, d in enumerate(M.booth_digits(k, sb, w)):
+            e = abs(d) << (w * i)
+            assert e <= top
+            if e == top:
+                assert i == nwin - 1 and d == 1 << shift
+                seen_special = True
+    assert seen_special

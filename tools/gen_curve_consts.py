@@ -11,7 +11,8 @@ generated values against tests/golden/params.json.
 import sys
 
 CURVES = [
-    # name, p, b, gx, gy, field bytes, scalar bytes, flavour(0 = a=-3, 1 = a=0)
+    # name, p, b, gx, gy, field bytes, scalar bytes, flavour(0 = a=-3, 1 = a=0); the order n of the
+    # generator is in ORDERS below (only its bit length reaches the kernels)
     ("P256", 2**256 - 2**224 + 2**192 + 2**96 - 1,
      0x5AC635D8AA3A93E7B3EBBD55769886BC651D06B0CC53B0F63BCE3C3E27D2604B,
      0x6B17D1F2E12C4247F8BCE6E563A440F277037D812DEB33A0F4A13945D898C296,
@@ -29,6 +30,14 @@ CURVES = [
      0x17F1D3A73197D7942695638C4FA9AC0FC3688C4F9774B905A14E3A3F171BAC586C55E83FF97A1AEFFB3AF00ADB22C6BB,
      0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744A2888AE40CAA232946C5E7E1, 48, 32, 1),
 ]
+
+# order of the generator (prime) and cofactor of the curve
+ORDERS = {
+    "P256": (0xFFFFFFFF00000000FFFFFFFFFFFFFFFFBCE6FAADA7179E84F3B9CAC2FC632551, 1),
+    "P384": (0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFC7634D81F4372DDF581A0DB248B0A77AECEC196ACCC52973, 1),
+    "P521": (0x01FFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFA51868783BF2F966B7FCC0148F709A5D03BB5C9B8899C47AEBB6FB71E91386409, 1),
+    "BLS12_381": (0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001, 0x396C8C005555E1568C00AAAB0000AAAB),
+}
 
 P25519 = 2**255 - 19
 ED_D = (-121665 * pow(121666, -1, P25519)) % P25519
@@ -107,7 +116,9 @@ def emit_field(out, p, L, mersenne=0, pm19=0):
     # to suffice for every odd modulus below 2^256 (convex-hull bound of github.com/sipa/safegcd-bounds, the
     # figure libsecp256k1's modinv32 relies on: 20 batches of 30) -- against 724 / 741 with delta = 1
     hd = p.bit_length() <= 256
-    out.append("  static constexpr bool INV30_HD = %s;  // division steps start at delta = 1/2" % ("true" if hd else "false"))
+    out.append("  static constexpr bool INV30_HD = %s;  // %s" % (
+        ("true", "division steps start at delta = 1/2 (590-step bound below 2^256)") if hd else
+        ("false", "division steps start at delta = 1 (Bernstein-Yang bound)")))
     out.append("  static constexpr int INV30_BATCHES = %d;" % (20 if hd else ((49 * p.bit_length() + 57) // 17 + 29) // 30))
     return R
 
@@ -244,6 +255,9 @@ def main():
         out.append("  static constexpr int FB = %d;  // field bytes" % fb)
         out.append("  static constexpr int SB = %d;  // scalar bytes" % sb)
         out.append("  static constexpr int A0 = %d;  // 1: a = 0 (uses B3), 0: a = -3 (uses B)" % a0)
+        order, cof = ORDERS[name]
+        out.append("  static constexpr int NBITS = %d;  // bit length of the generator's (prime) order" % order.bit_length())
+        out.append("  static constexpr int PRIME_ORDER = %d;  // 1: cofactor 1, every curve point has that order" % (1 if cof == 1 else 0))
         R = emit_field(out, p, L, 521 if name == "P521" else 0)
         out.append(arr("B", limbs(b * R % p, L)))
         out.append(arr("B3", limbs(3 * b * R % p, L)))

@@ -37,13 +37,17 @@ def main():
     ap.add_argument("kernel", help="substring of the demangled kernel name")
     ap.add_argument("--min-mads", type=int, default=150)
     ap.add_argument("--asm", help="reuse an assembly file instead of compiling")
+    ap.add_argument("--branches", action="store_true",
+                    help="list every conditional branch of the kernel with the instruction that produced its condition "
+                         "(the census behind the secret-scalar kernels' claim: no branch on scalar-derived data)")
+    ap.add_argument("--define", "-D", action="append", default=[], help="extra -D macro for the compile")
     args = ap.parse_args()
     asm = args.asm
     if not asm:
         asm = os.path.join(tempfile.mkdtemp(), "unit.s")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-mllvm",
                                "-pragma-unroll-threshold=1000000", "-S", "--cuda-device-only", os.path.join(CSRC, args.unit),
-                               "-o", asm], stderr=subprocess.DEVNULL)
+                               "-o", asm] + ["-D" + d for d in args.define], stderr=subprocess.DEVNULL)
     txt = open(asm).read()
     labels = re.findall(r"^(_Z\w+):", txt, flags=re.M)
     names = demangle(labels)
@@ -74,6 +78,9 @@ def main():
     blocks.append(cur)
     print(f"# {names[mangled].split('(')[0]}")
     print(f"# unit {args.unit}; resources: {meta}")
+    if args.branches:
+        branch_census(body)
+        return
     print("# block: instructions / VALU / multiplies; share of the block's issue cycles spent on multiplies")
     for name, c in blocks:
         mads = c["v_mad_u64_u32"] + c["v_mad_i64_i32"]
@@ -87,6 +94,51 @@ def main():
               f"({100.0 * mads / max(1, sum(valu.values())):.1f} % of VALU instructions, {100.0 * mad_cyc / cyc:.1f} % of VALU issue cycles)")
         for k, v in c.most_common():
             print(f"    {v:6d}  {k}")
+
+
+def branch_census(body):
+    """Every conditional branch, the instruction that last wrote the register it tests (scc / vcc / exec) and the
+    memory-instruction mix.  A scalar compare (s_cmp_*) can only see SGPRs: loop counters, kernel arguments and
+    values made wave-uniform beforehand (ballots, readlanes); those producers are listed too."""
+    mem = collections.Counter()
+    uniformisers = collections.Counter()
+    rows = []
+    block = "<entry>"
+    last = {"scc": "-", "vcc": "-", "exec": "-"}
+    for line in body:
+        m = re.match(r"^(\.LBB\w+):", line)
+        if m:
+            block = m.group(1)
+            continue
+        m = re.match(r"^\s+([a-z][a-z_0-9]*)\s*(.*)", line)
+        if not m:
+            continue
+        op, args = m.group(1), m.group(2).split(";")[0].strip()
+        if op.startswith(("global_", "buffer_", "flat_", "scratch_", "ds_", "s_load", "s_buffer_load")):
+            mem[op] += 1
+        if op.startswith(("v_readlane", "v_readfirstlane")) or "ballot" in op:
+            uniformisers[op] += 1
+        if op.startswith("s_cbranch"):
+            reg = "scc" if "scc" in op else ("vcc" if "vcc" in op else ("exec" if "exec" in op else "?"))
+            rows.append((block, op, args, last.get(reg, "-")))
+            continue
+        if op.startswith("s_cmp") or op.startswith("s_bitcmp") or (op.startswith("s_") and not op.startswith(("s_mov", "s_load", "s_waitcnt", "s_nop", "s_branch", "s_barrier", "s_cbranch")) and not op.startswith("s_cmp")):
+            # most SALU arithmetic writes scc as a side effect; remember the last one
+            last["scc"] = f"{op} {args}"
+        if op.startswith("v_cmp") and ("vcc" in args.split(",")[0] or "_e32" in op):
+            last["vcc"] = f"{op} {args}"
+        if "saveexec" in op or (op.startswith("s_") and args.startswith("exec")):
+            last["exec"] = f"{op} {args}"
+        if op.startswith("s_") and args.startswith("vcc"):
+            last["vcc"] = f"{op} {args}"
+    print(f"# {len(rows)} conditional branches")
+    for block, op, args, producer in rows:
+        print(f"  {block:14s} {op:18s} {args:12s} <- {producer}")
+    print("# wave-uniformising instructions (a branch on their results would be data-dependent):",
+          dict(uniformisers) if uniformisers else "none")
+    print("# memory instructions:")
+    for k, v in sorted(mem.items()):
+        print(f"    {v:6d}  {k}")
 
 
 if __name__ == "__main__":
