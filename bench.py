@@ -317,7 +317,7 @@ def main():
     ap.add_argument("--workload", default="p256r1_var_2^20", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1 << 17)
-    ap.add_argument("--variant", default="default", choices=["default", "mirror", "lds", "l2", "ct", "glv"],
+    ap.add_argument("--variant", default="default", choices=["default", "mirror", "lds", "l2", "ct", "ctg", "glv"],
                     help="default: fast kernels; mirror: reference-mirroring kernels; "
                          "lds: ed25519 fixed base with a signed 6-bit comb table resident in LDS; "
                          "l2: the reference's 4-bit comb read through L2; "
@@ -387,12 +387,13 @@ def main():
     pipe = GatherPipeline(n, out_cols, dev, slots=2, force=force_dist)
 
     mirror = args.variant == "mirror"
-    ct = args.variant == "ct"
+    ct = args.variant in ("ct", "ctg")
+    ctg = args.variant == "ctg"
     glv = args.variant == "glv"
     # one-time costs out of the timed region (and out of the _dev calls): tables + scratch
     if op in ("base", "dsm"):
-        eng.prepare(curve, base=True, base_lds=args.variant == "lds")
-    eng.reserve(curve, n, var=op in ("var", "dsm"), mirror=mirror or ct)
+        eng.prepare(curve, base=True, base_lds=args.variant == "lds", ct=ct and not ctg, ct_gather=ctg)
+    eng.reserve(curve, n, var=op in ("var", "dsm"), mirror=mirror or ct, ct=ct)
 
     def step(slot):
         out, flags = outs[slot], flagss[slot]
@@ -404,7 +405,7 @@ def main():
         elif op == "x25519":
             eng.x25519_t(ks, pts, out, flags, stream=stream.cuda_stream)
         else:
-            eng.scalarmul_base_t(curve, ks, out, flags, stream=stream.cuda_stream, mirror=mirror, ct_scan=ct,
+            eng.scalarmul_base_t(curve, ks, out, flags, stream=stream.cuda_stream, mirror=mirror, ct_scan=ct, ct_gather=ctg,
                                  table_in_lds={"lds": True, "l2": False}.get(args.variant))
 
     def run(steps, events=None):

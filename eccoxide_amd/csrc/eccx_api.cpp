@@ -53,6 +53,7 @@ struct eccx_ctx {
   uint32_t* comb_u[NCURVES] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // unsaturated-field copies
   uint32_t* comb_lds[NCURVES] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // images for the LDS variant
   uint32_t* comb_ct[NCURVES] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // signed-window tables of the secret-scalar path
+  uint32_t* comb_ctg[NCURVES] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // ... of its lane-gather form (ECCX_CT_GATHER)
   std::mutex comb_mu;
   uint32_t* scratch = nullptr;
   size_t scratch_words = 0;
@@ -353,23 +354,26 @@ int ensure_comb_lds(eccx_ctx* ctx, int curve, const CurveOps* ops, hipStream_t c
 // table of the secret-scalar fixed-base kernels (kernels_ct.hpp): entry (w, d) = d * 2^(ct_bits * w) * G for
 // d = 1 .. ct_entries, built by the engine's own variable-base path (the generator is public; digits the top
 // window cannot produce get the zero scalar and stay unused)
-int ensure_comb_ct(eccx_ctx* ctx, int curve, const CurveOps* ops, hipStream_t caller) {
+int ensure_comb_ct(eccx_ctx* ctx, int curve, const CurveOps* ops, hipStream_t caller, bool gather = false) {
   std::lock_guard<std::mutex> g(ctx->comb_mu);
-  if (ctx->comb_ct[curve]) return ECCX_OK;
-  if (!ops->base_ct || !ops->ct_convert) {
+  uint32_t** slot_ptr = gather ? &ctx->comb_ctg[curve] : &ctx->comb_ct[curve];
+  if (*slot_ptr) return ECCX_OK;
+  const int ct_bits = gather ? ops->ctg_bits : ops->ct_bits, ct_windows = gather ? ops->ctg_windows : ops->ct_windows,
+            ct_entries = gather ? ops->ctg_entries : ops->ct_entries;
+  if (!(gather ? ops->base_ctg : ops->base_ct) || !ops->ct_convert) {
     ctx->set_err("no secret-scalar fixed-base kernel for this curve");
     return ECCX_ERR_ARG;
   }
   (void)caller;
   HIP_TRY(ctx, hipDeviceSynchronize());  // as ensure_comb
-  const int sbytes = ops->info.sb, W = ops->ct_bits;
-  const size_t entries = (size_t)ops->ct_windows * ops->ct_entries, pb = 2 * (size_t)ops->info.fb;
+  const int sbytes = ops->info.sb, W = ct_bits;
+  const size_t entries = (size_t)ct_windows * ct_entries, pb = 2 * (size_t)ops->info.fb;
   // one more row: 2^(8 SB - 1) * G, from which the one reachable entry whose scalar does not fit SB bytes is made
   // below -- the top window's digit 2^(8 SB - W w_top) stands for 2^(8 SB) * G (a scalar of all ones recodes to it)
   std::vector<uint8_t> k((entries + 1) * sbytes, 0);
-  for (int w = 0; w < ops->ct_windows; ++w)
-    for (int d = 1; d <= ops->ct_entries; ++d) {
-      uint8_t* row = k.data() + ((size_t)w * ops->ct_entries + (size_t)(d - 1)) * sbytes;
+  for (int w = 0; w < ct_windows; ++w)
+    for (int d = 1; d <= ct_entries; ++d) {
+      uint8_t* row = k.data() + ((size_t)w * ct_entries + (size_t)(d - 1)) * sbytes;
       bool fits = true;
       for (int bit = 0; bit < 16; ++bit)
         if ((d >> bit) & 1) {
@@ -392,9 +396,9 @@ int ensure_comb_ct(eccx_ctx* ctx, int curve, const CurveOps* ops, hipStream_t ca
   int rc = launch_var(ctx, ops, entries + 1, d_k, nullptr, d_aff, d_fl, nullptr, K_BASE_IS_GENERATOR, false, ctx->stream);
   if (rc) return rc;
   {
-    const int w_top = ops->ct_windows - 1, shift = 8 * sbytes - W * w_top;  // 2^(8 SB) = 2^shift * 2^(W w_top)
-    if (shift >= 0 && shift < W && (1 << shift) <= ops->ct_entries) {
-      const size_t slot = (size_t)w_top * ops->ct_entries + (size_t)((1 << shift) - 1);
+    const int w_top = ct_windows - 1, shift = 8 * sbytes - W * w_top;  // 2^(8 SB) = 2^shift * 2^(W w_top)
+    if (shift >= 0 && shift < W && (1 << shift) <= ct_entries) {
+      const size_t slot = (size_t)w_top * ct_entries + (size_t)((1 << shift) - 1);
       rc = eccx_point_add_dev(ctx, curve, 1, d_aff + entries * pb, nullptr, d_aff + entries * pb, nullptr, d_aff + slot * pb,
                               d_fl + slot, 0, ctx->stream);  // the complete addition doubles
       if (rc) return rc;
@@ -403,7 +407,7 @@ int ensure_comb_ct(eccx_ctx* ctx, int curve, const CurveOps* ops, hipStream_t ca
   HIP_TRY(ctx, ops->ct_convert(ctx->stream, entries, d_aff, d_tab));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   mem.release(d_tab);
-  ctx->comb_ct[curve] = d_tab;
+  *slot_ptr = d_tab;
   ctx->table_bytes += tab_bytes;
   return ECCX_OK;
 }
@@ -592,6 +596,8 @@ void eccx_shutdown(eccx_ctx* ctx) {
     if (t) (void)hipFree(t);
   for (auto& t : ctx->comb_ct)
     if (t) (void)hipFree(t);
+  for (auto& t : ctx->comb_ctg)
+    if (t) (void)hipFree(t);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->jac) (void)hipFree(ctx->jac);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -635,7 +641,8 @@ int eccx_prepare(eccx_ctx* ctx, int curve, uint32_t what) {
     }
     rc = ensure_comb_lds(ctx, curve, ops, ctx->stream);
   }
-  if (!rc && (what & ECCX_PREP_CT)) rc = ensure_comb_ct(ctx, curve, ops, ctx->stream);
+  if (!rc && (what & ECCX_PREP_CT)) rc = ensure_comb_ct(ctx, curve, ops, ctx->stream, false);
+  if (!rc && (what & ECCX_PREP_CT_GATHER)) rc = ensure_comb_ct(ctx, curve, ops, ctx->stream, true);
   return rc;
 }
 
@@ -725,13 +732,15 @@ int eccx_scalarmul_base_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_sc
       ctx->set_err("ECCX_CT_SCAN | ECCX_TABLE_IN_LDS: the LDS-resident comb indexes its table by the digit");
       return ECCX_ERR_ARG;
     }
-    rc = ensure_comb_ct(ctx, curve, ops, s);
+    const bool gather = (opts & ECCX_CT_GATHER) != 0 && ops->base_ctg;
+    rc = ensure_comb_ct(ctx, curve, ops, s, gather);
     if (rc) return rc;
     rc = ensure_rows(ctx, ops, n);
     if (rc) return rc;
     const int cgrid = (int)std::max<size_t>(1, std::min(need, (size_t)ctx->cus * 16));
-    HIP_TRY(ctx, ops->base_ct(cgrid, s, n, static_cast<const uint8_t*>(d_scalars), ctx->comb_ct[curve], ctx->jac,
-                              static_cast<uint8_t*>(d_flags)));
+    HIP_TRY(ctx, (gather ? ops->base_ctg : ops->base_ct)(cgrid, s, n, static_cast<const uint8_t*>(d_scalars),
+                                                         gather ? ctx->comb_ctg[curve] : ctx->comb_ct[curve], ctx->jac,
+                                                         static_cast<uint8_t*>(d_flags)));
     HIP_TRY(ctx, ops->to_affine_var(norm_grid(ctx, n), s, n, ctx->jac, static_cast<uint8_t*>(d_out),
                                     static_cast<uint8_t*>(d_flags)));
     return ECCX_OK;

@@ -100,7 +100,12 @@ hipError_t ct_convert_(hipStream_t s, size_t entries, const uint8_t* affine, uin
 }
 hipError_t base_ct_(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint32_t* table, uint32_t* rows,
                     uint8_t* flags) {
-  hipLaunchKernelGGL(k_ed_scalarmul_base_ct<ED25519U>, dim3(grid), dim3(WG), 0, s, n, scalars, table, rows, flags);
+  hipLaunchKernelGGL((k_ed_scalarmul_base_ct<ED25519U, false>), dim3(grid), dim3(WG), 0, s, n, scalars, table, rows, flags);
+  return hipGetLastError();
+}
+hipError_t base_ctg_(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint32_t* table, uint32_t* rows,
+                     uint8_t* flags) {
+  hipLaunchKernelGGL((k_ed_scalarmul_base_ct<ED25519U, true>), dim3(grid), dim3(WG), 0, s, n, scalars, table, rows, flags);
   return hipGetLastError();
 }
 }  // namespace
@@ -125,6 +130,10 @@ const CurveOps& ops_ED25519() {
     t.ct_entry_words = ct_entry_words<ED25519U>();
     t.ct_convert = ct_convert_;
     t.base_ct = base_ct_;
+    t.ctg_bits = ct_base_bits<ED25519U, true>();
+    t.ctg_windows = ct_base_windows<ED25519U, true>();
+    t.ctg_entries = ct_base_entries<ED25519U, true>();
+    t.base_ctg = base_ctg_;
     return t;
   }();
   return o;

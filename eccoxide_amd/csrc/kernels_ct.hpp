@@ -27,6 +27,17 @@
 //             string, canonical or not); tests/test_ct_model.py checks the bound by enumeration on
 //             small parameters.
 //
+//   gather    (GATHER = true, ECCX_CT_GATHER) the lookup as a cross-lane move instead of a scan: lane l of every
+//             wavefront loads entry l of the window's slice -- an address that depends on the lane number only --
+//             and each lane then fetches the words of "its" entry from lane d - 1 with ds_bpermute_b32, which
+//             routes registers through the LDS crossbar and touches no memory.  No address and no branch depends
+//             on a digit; what the digit steers is the crossbar.  Its time was measured the same for identity,
+//             random, all-equal and bank-folding index patterns (97-100 cycles per four permutes either way,
+//             profiles/r03_select_rates.jsonl), but that is a measurement, not an architectural guarantee: the
+//             strict scan stays the default of ECCX_CT_SCAN and this form is opt-in.  A permute costs no VALU
+//             slot and the same whatever the number of entries, so the windows are 7 bits wide (64 entries, one
+//             per lane; 37 additions for 256 bits).
+//
 // Everything a lane does is the same instruction stream whatever its scalar; the only branches are loop
 // counters and the bounds of the batch.  tools/isa_histogram.py --branches lists them per kernel.
 #pragma once
@@ -34,23 +45,59 @@
 
 namespace eccx {
 
+// Window width of the scanning comb.  Measured per 2^20 units (same box, profiles/r03_ab_ct.txt): p256r1 W = 4 / 5 / 6:
+// 3.96 / 3.50 / 3.30 ms, ed25519 2.66 / 2.46 / 2.58 ms -- the scan costs 4.5-5 cycles per word and entry
+// (v_cndmask_b32_e64), the Edwards addition is cheaper and its entries are three coordinates wide.
 #ifndef ECCX_CT_BASE_BITS
 #define ECCX_CT_BASE_BITS 6
 #endif
+#ifndef ECCX_CT_BASE_BITS_ED
+#define ECCX_CT_BASE_BITS_ED 5
+#endif
+#ifndef ECCX_CT_BASE_OCC9
+#define ECCX_CT_BASE_OCC9 4
+#endif
+#ifndef ECCX_CT_GATHER_BITS
+#define ECCX_CT_GATHER_BITS 7
+#endif
+template <class CU, bool GATHER = false>
+constexpr int ct_base_bits() { return GATHER ? ECCX_CT_GATHER_BITS : (CU::KIND == UK_PM19 ? ECCX_CT_BASE_BITS_ED : ECCX_CT_BASE_BITS); }
+// waves per SIMD the comb is compiled for (the XYZZ accumulator is four coordinates)
 template <class CU>
-constexpr int ct_base_bits() { return ECCX_CT_BASE_BITS; }
-template <class CU>
-constexpr int ct_base_windows() { return (8 * CU::Sat::SB + 1 + ct_base_bits<CU>() - 1) / ct_base_bits<CU>(); }
-template <class CU>
-constexpr int ct_base_entries() { return 1 << (ct_base_bits<CU>() - 1); }
+constexpr int ct_base_occupancy() { return CU::N <= 9 ? ECCX_CT_BASE_OCC9 : unsat_occupancy<CU>(); }
+template <class CU, bool GATHER = false>
+constexpr int ct_base_windows() { return (8 * CU::Sat::SB + 1 + ct_base_bits<CU, GATHER>() - 1) / ct_base_bits<CU, GATHER>(); }
+template <class CU, bool GATHER = false>
+constexpr int ct_base_entries() { return 1 << (ct_base_bits<CU, GATHER>() - 1); }
 // words per table entry, padded to 16 bytes: Weierstrass (x, y), edwards25519 (y - x, y + x, 2d x y)
 template <class CU>
 constexpr int ct_entry_words() { return (((CU::KIND == UK_PM19 ? 3 : 2) * CU::N + 3) / 4) * 4; }
 // windows (counted from the top) in which accumulator == +-entry is possible: those with W (w + 1) >= NBITS
-template <class CU>
+template <class CU, bool GATHER = false>
 constexpr int ct_unsafe_windows() {
-  constexpr int W = ct_base_bits<CU>();
-  return ct_base_windows<CU>() - ((CU::Sat::NBITS + W - 1) / W) + 1;
+  constexpr int W = ct_base_bits<CU, GATHER>();
+  return ct_base_windows<CU, GATHER>() - ((CU::Sat::NBITS + W - 1) / W) + 1;
+}
+
+// The gather form of the lookup: lane l holds entry (l mod ENT) of the window's slice (loaded from an address
+// that depends on the lane number only); every lane takes the EW words of entry d from lane d - 1 -- in its own
+// half of the wavefront when two copies of a 32-entry slice fit the 64 lanes.  Digit 0 reads some lane's entry;
+// the caller discards it.
+template <int EW, int ENT>
+ECCX_DEV void ct_gather_lanes(uint32_t (&out)[EW], const uint4* __restrict__ slice, uint32_t d) {
+  static_assert(EW % 4 == 0 && (ENT == 64 || ENT == 32 || ENT == 16), "one entry per lane, whole copies per wavefront");
+  const uint32_t lane = threadIdx.x & 63u;
+  uint4 v[EW / 4];
+#pragma unroll
+  for (int c = 0; c < EW / 4; ++c) v[c] = slice[(lane & (uint32_t)(ENT - 1)) * (EW / 4) + c];
+  const int addr = (int)((((d - 1u) & (uint32_t)(ENT - 1)) | (lane & (uint32_t)(64 - ENT) & 63u)) << 2);
+#pragma unroll
+  for (int c = 0; c < EW / 4; ++c) {
+    out[4 * c] = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)v[c].x);
+    out[4 * c + 1] = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)v[c].y);
+    out[4 * c + 2] = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)v[c].z);
+    out[4 * c + 3] = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)v[c].w);
+  }
 }
 
 // select_from_table over a slice held in LDS: every lane reads entries 1 .. ENT (uniform addresses)
@@ -58,14 +105,14 @@ constexpr int ct_unsafe_windows() {
 template <int EW, int ENT>
 ECCX_DEV void ct_scan_lds(uint32_t (&out)[EW], const uint4* __restrict__ slice, uint32_t d) {
   static_assert(EW % 4 == 0, "entries are padded to 16 bytes");
-#pragma unroll 4
+#pragma unroll 2
   for (int j = 0; j < ENT; ++j) {
     const uint64_t m = __builtin_amdgcn_uicmp(d, (uint32_t)(j + 1), 32 /* ICMP_EQ */);
+    uint4 v[EW / 4];  // the whole entry first: its reads are in flight together
 #pragma unroll
-    for (int c = 0; c < EW / 4; ++c) {
-      const uint4 v = slice[j * (EW / 4) + c];
-      ct_cmov4(out[4 * c], out[4 * c + 1], out[4 * c + 2], out[4 * c + 3], v.x, v.y, v.z, v.w, m);
-    }
+    for (int c = 0; c < EW / 4; ++c) v[c] = slice[j * (EW / 4) + c];
+#pragma unroll
+    for (int c = 0; c < EW / 4; ++c) ct_cmov4(out[4 * c], out[4 * c + 1], out[4 * c + 2], out[4 * c + 3], v[c].x, v[c].y, v[c].z, v[c].w, m);
   }
 }
 
@@ -182,23 +229,23 @@ __global__ void k_affine_to_cttable(size_t entries, const uint8_t* __restrict__ 
 // mul_base_table_{am3,a0}, projective.rs:945-981).  table: ct_base_windows() slices of ct_base_entries()
 // entries of ct_entry_words() words; rows (X ZZ, Y ZZZ, ZZ) are Jacobian rows for
 // k_batch_to_affine_unsat<NORM_JACOBIAN>.
-template <class CU>
-__global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_base_ct(size_t n, const uint8_t* __restrict__ scalars,
+template <class CU, bool GATHER = false>
+__global__ void __launch_bounds__(WG, ct_base_occupancy<CU>()) k_scalarmul_base_ct(size_t n, const uint8_t* __restrict__ scalars,
                                                                                const uint32_t* __restrict__ table,
                                                                                uint32_t* __restrict__ rows_out,
                                                                                uint8_t* __restrict__ flags) {
   using CS = typename CU::Sat;
   constexpr int N = CU::N;
   constexpr int SB = CS::SB;
-  constexpr int W = ct_base_bits<CU>();
-  constexpr int NWIN = ct_base_windows<CU>();
-  constexpr int ENT = ct_base_entries<CU>();
+  constexpr int W = ct_base_bits<CU, GATHER>();
+  constexpr int NWIN = ct_base_windows<CU, GATHER>();
+  constexpr int ENT = ct_base_entries<CU, GATHER>();
   constexpr int EW = ct_entry_words<CU>();
   constexpr int SLICE4 = ENT * EW / 4;
-  constexpr int UNSAFE = ct_unsafe_windows<CU>();
+  constexpr int UNSAFE = ct_unsafe_windows<CU, GATHER>();
   static_assert(UNSAFE >= 1 && UNSAFE <= NWIN, "window bookkeeping");
   using T = U<CU, 1, 3>;
-  __shared__ uint4 lds[2][SLICE4];
+  __shared__ uint4 lds[GATHER ? 1 : 2][GATHER ? 1 : SLICE4];
   const uint4* __restrict__ gtab = reinterpret_cast<const uint4*>(table);
   T one;
 #pragma unroll
@@ -209,24 +256,32 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_base_ct
     const size_t idx = active ? gid : n - 1;
     const uint8_t* __restrict__ k = scalars + idx * (size_t)SB;
     CtSliceStage<SLICE4> stage;
-    stage.load(gtab);
-    __syncthreads();  // the previous batch's last reads of buffer 0 are done
-    stage.store(lds[0]);
-    __syncthreads();
+    if constexpr (!GATHER) {
+      stage.load(gtab);
+      __syncthreads();  // the previous batch's last reads of buffer 0 are done
+      stage.store(lds[0]);
+      __syncthreads();
+    }
     UXyzz<CU> q;
     q.x = one;
     q.y = one;
     u_set_zero(q.zz);
     u_set_zero(q.zzz);
     for (int w = 0; w < NWIN; ++w) {
-      if (w + 1 < NWIN) stage.load(gtab + (size_t)(w + 1) * SLICE4);
+      if constexpr (!GATHER) {
+        if (w + 1 < NWIN) stage.load(gtab + (size_t)(w + 1) * SLICE4);
+      }
       uint32_t d;
       bool neg;
       booth_digit<W, SB>(k, w, d, neg);
       uint32_t ew[EW];
+      if constexpr (GATHER) {
+        ct_gather_lanes<EW, ENT>(ew, gtab + (size_t)w * SLICE4, d);
+      } else {
 #pragma unroll
-      for (int i = 0; i < EW; ++i) ew[i] = 0;
-      ct_scan_lds<EW, ENT>(ew, lds[w & 1], d);
+        for (int i = 0; i < EW; ++i) ew[i] = 0;
+        ct_scan_lds<EW, ENT>(ew, lds[w & 1], d);
+      }
       T x2, y2;
 #pragma unroll
       for (int i = 0; i < N; ++i) { x2.v[i] = ew[i]; y2.v[i] = ew[N + i]; }
@@ -269,8 +324,10 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_base_ct
       u_cmov_ct(q.y, mk, sum.y);
       u_cmov_ct(q.zz, mk, sum.zz);
       u_cmov_ct(q.zzz, mk, sum.zzz);
-      if (w + 1 < NWIN) stage.store(lds[(w + 1) & 1]);
-      __syncthreads();
+      if constexpr (!GATHER) {
+        if (w + 1 < NWIN) stage.store(lds[(w + 1) & 1]);
+        __syncthreads();
+      }
     }
     if (active) {
       // (X, Y, ZZ, ZZZ) -> the Jacobian triple (X ZZ : Y ZZZ : ZZ): X ZZ / ZZ^2 = x, Y ZZZ / ZZ^3 = Y / ZZZ = y
@@ -283,18 +340,18 @@ __global__ void __launch_bounds__(WG, unsat_occupancy<CU>()) k_scalarmul_base_ct
 // ---- edwards25519 fixed base, secret scalars (curve25519.rs:840-869) -----------------------------------
 // Complete additions: digit 0 adds the neutral element (1, 1, 0), which is what the scan leaves when no
 // entry matches; a negative digit swaps y - x with y + x and negates 2d x y.
-template <class CU>
+template <class CU, bool GATHER = false>
 __global__ void __launch_bounds__(WG, 4) k_ed_scalarmul_base_ct(size_t n, const uint8_t* __restrict__ scalars,
                                                                 const uint32_t* __restrict__ table,
                                                                 uint32_t* __restrict__ rows_out, uint8_t* __restrict__ flags) {
   constexpr int N = CU::N;
-  constexpr int W = ct_base_bits<CU>();
-  constexpr int NWIN = ct_base_windows<CU>();
-  constexpr int ENT = ct_base_entries<CU>();
+  constexpr int W = ct_base_bits<CU, GATHER>();
+  constexpr int NWIN = ct_base_windows<CU, GATHER>();
+  constexpr int ENT = ct_base_entries<CU, GATHER>();
   constexpr int EW = ct_entry_words<CU>();
   constexpr int SLICE4 = ENT * EW / 4;
   using T = U<CU, 1, 3>;
-  __shared__ uint4 lds[2][SLICE4];
+  __shared__ uint4 lds[GATHER ? 1 : 2][GATHER ? 1 : SLICE4];
   const uint4* __restrict__ gtab = reinterpret_cast<const uint4*>(table);
   for (size_t base = (size_t)blockIdx.x * WG; base < n; base += (size_t)gridDim.x * WG) {
     const size_t gid = base + threadIdx.x;
@@ -302,24 +359,36 @@ __global__ void __launch_bounds__(WG, 4) k_ed_scalarmul_base_ct(size_t n, const 
     const size_t idx = active ? gid : n - 1;
     const uint8_t* __restrict__ k = scalars + idx * 32;
     CtSliceStage<SLICE4> stage;
-    stage.load(gtab);
-    __syncthreads();
-    stage.store(lds[0]);
-    __syncthreads();
+    if constexpr (!GATHER) {
+      stage.load(gtab);
+      __syncthreads();
+      stage.store(lds[0]);
+      __syncthreads();
+    }
     T qx, qy, qz, qt;  // the neutral element (0, 1, 1, 0)
     u_set_zero(qx); u_set_zero(qy); u_set_zero(qz); u_set_zero(qt);
     qy.v[0] = 1; qz.v[0] = 1;
     for (int w = 0; w < NWIN; ++w) {
-      if (w + 1 < NWIN) stage.load(gtab + (size_t)(w + 1) * SLICE4);
+      if constexpr (!GATHER) {
+        if (w + 1 < NWIN) stage.load(gtab + (size_t)(w + 1) * SLICE4);
+      }
       uint32_t d;
       bool neg;
       booth_digit<W, 32>(k, w, d, neg);
       uint32_t ew[EW];
+      if constexpr (GATHER) {
+        ct_gather_lanes<EW, ENT>(ew, gtab + (size_t)w * SLICE4, d);
+        // digit 0: the neutral element (1, 1, 0) instead of whatever lane ENT - 1 holds
+        const uint64_t mz = ct_mask(d == 0);
 #pragma unroll
-      for (int i = 0; i < EW; ++i) ew[i] = 0;
-      ew[0] = 1;  // y - x
-      ew[N] = 1;  // y + x
-      ct_scan_lds<EW, ENT>(ew, lds[w & 1], d);
+        for (int i = 0; i < 3 * N; ++i) ct_cmov1(ew[i], (i == 0 || i == N) ? 1u : 0u, mz);
+      } else {
+#pragma unroll
+        for (int i = 0; i < EW; ++i) ew[i] = 0;
+        ew[0] = 1;  // y - x
+        ew[N] = 1;  // y + x
+        ct_scan_lds<EW, ENT>(ew, lds[w & 1], d);
+      }
       T a, b, t2d, ym, yp;
 #pragma unroll
       for (int i = 0; i < N; ++i) { a.v[i] = ew[i]; b.v[i] = ew[N + i]; t2d.v[i] = ew[2 * N + i]; }
@@ -328,8 +397,10 @@ __global__ void __launch_bounds__(WG, 4) k_ed_scalarmul_base_ct(size_t n, const 
       U<CU, 2, 4> t2;
       u_select_ct(t2, neg, u_neg(t2d), u_as<2, 4>(t2d));
       ued_add_niels<CU, 2, 4>(qx, qy, qz, qt, ym, yp, t2);
-      if (w + 1 < NWIN) stage.store(lds[(w + 1) & 1]);
-      __syncthreads();
+      if constexpr (!GATHER) {
+        if (w + 1 < NWIN) stage.store(lds[(w + 1) & 1]);
+        __syncthreads();
+      }
     }
     if (active) {
       u3_store<CU>(rows_out + idx * (size_t)urow3_words<CU>(), qx, qy, qz);

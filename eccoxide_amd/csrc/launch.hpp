@@ -103,10 +103,14 @@ struct CurveOps {
   //   var_ct    variable base, Weierstrass (null for edwards25519): the affine-table ladder with every table
   //             row read at every lookup; slab rows of coz_row_words; rows for to_affine_var; units marked
   //             0xFE (from the base point alone) are redone by `var` with the scan and only-marked options
+  //   base_ctg  the same with the lookup as a cross-lane gather (ECCX_CT_GATHER): its own table, ctg_bits-wide windows
   int ct_bits, ct_windows, ct_entries, ct_entry_words;
+  int ctg_bits, ctg_windows, ctg_entries;
   hipError_t (*ct_convert)(hipStream_t s, size_t entries, const uint8_t* affine, uint32_t* table);
   hipError_t (*base_ct)(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint32_t* table, uint32_t* rows,
                         uint8_t* flags);
+  hipError_t (*base_ctg)(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint32_t* table, uint32_t* rows,
+                         uint8_t* flags);
   hipError_t (*var_ct)(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint8_t* points, uint32_t* rows,
                        uint8_t* flags, uint32_t* scratch, uint32_t opts);
   int (*var_ct_grid)(int cus, size_t n);

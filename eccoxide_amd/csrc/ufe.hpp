@@ -787,25 +787,28 @@ ECCX_DEV bool u_is_zero_mod_p_ct(const U<C, 1, 3>& a) {
 // ---- selects the compiler cannot turn into control flow (secret-scalar kernels) -----------------------
 // hipcc is free to compile `take ? a : b` as an EXEC-masked region with an s_cbranch_execz around whatever
 // feeds it (it does: a table scan written with ?: came out with its LDS reads inside such regions, skipped
-// when no lane of the wave takes the entry -- a branch on scalar digits).  These forms are opaque: the lane
-// mask goes to VCC and the data through v_cndmask_b32 inside one asm volatile statement, so both operands
-// are always computed, every load that feeds them is always issued, and nothing is skipped.
+// when no lane of the wave takes the entry -- a branch on scalar digits).  These forms are opaque: the data
+// goes through v_cndmask_b32 inside an asm statement, so both operands are always computed, every load that
+// feeds them is always issued, and nothing is skipped.  (Not `volatile`:
+// a volatile asm is a scheduling barrier, and a scan whose every 16-byte load waits for the select before it
+// runs at LDS latency -- measured 5x slower.  Without it the statement is still opaque and still consumes both
+// operands wherever it executes; tools/isa_histogram.py --branches is the check that no conditional branch
+// was built around any of them.)
 ECCX_DEV uint64_t ct_mask(bool take) { return __builtin_amdgcn_uicmp((uint32_t)take, 1u, 32 /* ICMP_EQ */); }
-// o[i] = lane in m ? a[i] : o[i], four words
+// o[i] = lane in m ? a[i] : o[i], four words.  The mask stays in an SGPR pair and the select is the VOP3 form:
+// on gfx950 a v_cndmask_b32 that takes its mask from VCC issues every 16-18 cycles, the same instruction with
+// an SGPR-pair mask (or v_bfi_b32 with a VGPR mask) every 4.5-5 (profiles/r03_select_rates.jsonl).
 ECCX_DEV void ct_cmov4(uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3, uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3,
                        uint64_t m) {
-  asm volatile(
-      "s_mov_b64 vcc, %8\n\t"
-      "v_cndmask_b32_e32 %0, %0, %4, vcc\n\t"
-      "v_cndmask_b32_e32 %1, %1, %5, vcc\n\t"
-      "v_cndmask_b32_e32 %2, %2, %6, vcc\n\t"
-      "v_cndmask_b32_e32 %3, %3, %7, vcc"
+  asm("v_cndmask_b32_e64 %0, %0, %4, %8\n\t"
+      "v_cndmask_b32_e64 %1, %1, %5, %8\n\t"
+      "v_cndmask_b32_e64 %2, %2, %6, %8\n\t"
+      "v_cndmask_b32_e64 %3, %3, %7, %8"
       : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3)
-      : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "s"(m)
-      : "vcc");
+      : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "s"(m));
 }
 ECCX_DEV void ct_cmov1(uint32_t& o, uint32_t a, uint64_t m) {
-  asm volatile("s_mov_b64 vcc, %2\n\tv_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(o) : "v"(a), "s"(m) : "vcc");
+  asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(o) : "v"(a), "s"(m));
 }
 // r = take ? a : r
 template <class C, int K, int V>

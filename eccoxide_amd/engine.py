@@ -23,7 +23,8 @@ CHECK_SUBGROUP = 1 << 6
 UNCOMPRESSED = 1 << 7
 CT_SCAN = 1 << 8
 ASSUME_SUBGROUP = 1 << 9
-PREP_VAR, PREP_BASE, PREP_BASE_LDS, PREP_MIRROR, PREP_CT = 1, 2, 4, 8, 16
+CT_GATHER = 1 << 10
+PREP_VAR, PREP_BASE, PREP_BASE_LDS, PREP_MIRROR, PREP_CT, PREP_CT_GATHER = 1, 2, 4, 8, 16, 32
 FLAG_FINITE, FLAG_INFINITY, FLAG_REJECTED = 0, 1, 2
 
 
@@ -115,12 +116,12 @@ class Engine:
         return t.numel() // width
 
     # ---- one-time costs ------------------------------------------------------
-    def prepare(self, curve, *, base: bool = True, base_lds: bool = False, ct: bool = False):
+    def prepare(self, curve, *, base: bool = True, base_lds: bool = False, ct: bool = False, ct_gather: bool = False):
         """eccx_prepare: build the fixed-base tables of `curve` now (blocking); ct: the signed-window table
         of the secret-scalar (ECCX_CT_SCAN) fixed-base kernel."""
         self._check(self._lib.eccx_prepare(self._ctx, curve_id(curve),
                                            (PREP_BASE if base else 0) | (PREP_BASE_LDS if base_lds else 0)
-                                           | (PREP_CT if ct else 0)))
+                                           | (PREP_CT if ct else 0) | (PREP_CT_GATHER if ct_gather else 0)))
 
     def reserve(self, curve, max_n: int, *, var: bool = True, mirror: bool = False, ct: bool = False):
         """eccx_reserve: size the scratch slab and row buffer for batches of up to max_n units; ct: for the
@@ -158,7 +159,7 @@ class Engine:
         return res + (proj.raw[: n * _proj_width(cid)],) if want_proj else res
 
     def scalarmul_base(self, curve, scalars: bytes, *, want_proj: bool = False, mirror: bool = False,
-                       ct_scan: bool = False):
+                       ct_scan: bool = False, ct_gather: bool = False):
         """out[i] = scalars[i] * G via the fixed-base comb table.
         mirror=True (implied by want_proj) runs the reference-mirroring kernels; ct_scan=True the
         reference's 4-bit comb with the full-table scan (secret scalars)."""
@@ -171,7 +172,8 @@ class Engine:
         flags = ctypes.create_string_buffer(max(1, n))
         proj = ctypes.create_string_buffer(max(1, n * _proj_width(cid))) if want_proj else None
         rc = self._lib.eccx_scalarmul_base(self._ctx, cid, n, scalars, out, flags, proj,
-                                           (MIRROR_REFERENCE if mirror else 0) | (CT_SCAN if ct_scan else 0))
+                                           (MIRROR_REFERENCE if mirror else 0) | (CT_SCAN if ct_scan or ct_gather else 0)
+                                           | (CT_GATHER if ct_gather else 0))
         self._check(rc)
         res = (out.raw[: n * 2 * fb], flags.raw[:n])
         return res + (proj.raw[: n * _proj_width(cid)],) if want_proj else res
@@ -396,7 +398,8 @@ class Engine:
         return out, flags
 
     def scalarmul_base_t(self, curve, scalars, out=None, flags=None, proj=None, *, stream: Optional[int] = None,
-                         table_in_lds: Optional[bool] = None, mirror: bool = False, ct_scan: bool = False):
+                         table_in_lds: Optional[bool] = None, mirror: bool = False, ct_scan: bool = False,
+                         ct_gather: bool = False):
         import torch
 
         cid = curve_id(curve)
@@ -413,7 +416,8 @@ class Engine:
         rc = self._lib.eccx_scalarmul_base_dev(self._ctx, cid, n, scalars.data_ptr(), out.data_ptr(),
                                                flags.data_ptr(), proj.data_ptr() if proj is not None else None,
                                                (0 if table_in_lds is None else (TABLE_IN_LDS if table_in_lds else TABLE_IN_L2))
-                                               | (MIRROR_REFERENCE if mirror else 0) | (CT_SCAN if ct_scan else 0),
+                                               | (MIRROR_REFERENCE if mirror else 0) | (CT_SCAN if ct_scan or ct_gather else 0)
+                                               | (CT_GATHER if ct_gather else 0),
                                                stream)
         self._check(rc)
         return out, flags

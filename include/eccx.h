@@ -129,6 +129,12 @@ enum {
                                       (src/curve/projective.rs:427-434, curve25519.rs:862-869): no memory
                                       address and no branch depends on a scalar digit.  Same bytes out.
                                       Not accepted by eccx_double_scalarmul (public data). */
+  ECCX_CT_GATHER = 1u << 10,       /* with ECCX_CT_SCAN, eccx_scalarmul_base: look the window's entry up by a cross-lane
+                                      gather (ds_bpermute_b32 from the lane that holds the entry) instead of the scan of the
+                                      whole window.  Still no memory address and no branch that depends on a digit; the
+                                      digit steers the wavefront's register crossbar, whose time was MEASURED the same for
+                                      every index pattern tried (profiles/r03_select_rates.jsonl) -- not an architectural
+                                      guarantee, hence opt-in.  About 1.4x faster than the scan. */
   ECCX_ASSUME_SUBGROUP = 1u << 9   /* eccx_scalarmul_var, bls12_381_g1: the caller guarantees every base point
                                       is in the prime-order subgroup G1 (e.g. it was decoded under
                                       ECCX_CHECK_SUBGROUP, or is a multiple of the generator).  The
@@ -143,6 +149,7 @@ enum {
   ECCX_PREP_BASE = 1u << 1,     /* fixed base and double-scalar: the comb tables of the curve */
   ECCX_PREP_BASE_LDS = 1u << 2, /* ECCX_TABLE_IN_LDS image (edwards25519) */
   ECCX_PREP_MIRROR = 1u << 3,   /* ECCX_MIRROR_REFERENCE / proj: slab of the mirror ladder */
+  ECCX_PREP_CT_GATHER = 1u << 5, /* ECCX_CT_SCAN | ECCX_CT_GATHER: eccx_prepare builds that form's table */
   ECCX_PREP_CT = 1u << 4        /* ECCX_CT_SCAN: eccx_prepare builds the signed-window table of the secret-scalar
                                    fixed-base kernel (99-460 KB); eccx_reserve sizes the slabs of the scanning
                                    variable-base ladder and of its fix-up pass */

@@ -24,8 +24,10 @@ pytestmark = pytest.mark.gpu
 WEI = ["p256r1", "p384r1", "p521r1", "bls12_381_g1"]
 ALL = WEI + ["ed25519"]
 _SIZES = {"p256r1": (32, 32), "p384r1": (48, 48), "p521r1": (66, 66), "bls12_381_g1": (48, 32), "ed25519": (32, 32)}
-CT_BASE_BITS = 6  # ECCX_CT_BASE_BITS
-CT_VAR_BITS = 4   # ECCX_CT_VAR_BITS
+CT_BASE_BITS = 6    # ECCX_CT_BASE_BITS (edwards25519: 5; it has no collision cases)
+CT_GATHER_BITS = 7  # ECCX_CT_GATHER_BITS
+CT_VAR_BITS = 4     # ECCX_CT_VAR_BITS
+LOOKUPS = [{"ct_scan": True}, {"ct_gather": True}]  # the strict scan and the opt-in cross-lane gather
 
 
 def _bases(oracle, curve, n, seed):
@@ -42,7 +44,7 @@ def _edge_scalars(curve):
     top = 1 << (8 * sb)
     vals = [0, 1, 2, 3, order - 1, order, order + 1, order - 2, top - 1, top - 2, top >> 1, (top >> 1) - 1, (top >> 1) + 1]
     # every window alone at its extreme digits, for both window widths in use
-    for w in (CT_BASE_BITS, CT_VAR_BITS, 5):
+    for w in (CT_BASE_BITS, CT_GATHER_BITS, CT_VAR_BITS, 5):
         for i in range(0, (8 * sb + w) // w):
             for d in (1, (1 << (w - 1)) - 1, 1 << (w - 1), (1 << (w - 1)) + 1, (1 << w) - 1):
                 v = d << (w * i)
@@ -53,29 +55,33 @@ def _edge_scalars(curve):
     return [v for v in vals if 0 <= v < top]
 
 
+@pytest.mark.parametrize("lookup", LOOKUPS, ids=["scan", "gather"])
 @pytest.mark.parametrize("curve", ALL)
-def test_ct_fixed_base_edge_scalars(engine, oracle, curve):
+def test_ct_fixed_base_edge_scalars(engine, oracle, curve, lookup):
     fb, sb = _SIZES[curve]
     ks = _pack(_edge_scalars(curve), sb)
     want = oracle.base(curve, ks, threads=16)
-    got = engine.scalarmul_base(curve, ks, ct_scan=True)
+    got = engine.scalarmul_base(curve, ks, **lookup)
     assert got[0] == want[0] and got[1] == want[1]
 
 
 @pytest.mark.parametrize("curve", WEI)
 def test_ct_fixed_base_collision_scalars(engine, oracle, curve):
     """Scalars for which the comb's accumulator meets +-(its next table entry): the select-only doubling
-    (from the entry's affine coordinates) and cancellation of the top windows."""
+    (from the entry's affine coordinates) and cancellation of the top windows -- found for both window widths."""
     fb, sb = _SIZES[curve]
     order = W.order(curve)
-    found = M.collision_scalars_fixed_base(sb, CT_BASE_BITS, order, limit=24)
-    kinds = {kind for ev in found.values() for _, kind in ev}
-    assert "cancel" in kinds  # k = n is always there
-    vals = sorted(found)
-    ks = _pack(vals, sb)
+    vals = set()
+    for bits in (CT_BASE_BITS, CT_GATHER_BITS):
+        found = M.collision_scalars_fixed_base(sb, bits, order, limit=24)
+        kinds = {kind for ev in found.values() for _, kind in ev}
+        assert "cancel" in kinds  # k = n is always there
+        vals |= set(found)
+    ks = _pack(sorted(vals), sb)
     want = oracle.base(curve, ks, threads=16)
-    got = engine.scalarmul_base(curve, ks, ct_scan=True)
-    assert got[0] == want[0] and got[1] == want[1]
+    for lookup in LOOKUPS:
+        got = engine.scalarmul_base(curve, ks, **lookup)
+        assert got[0] == want[0] and got[1] == want[1]
     assert engine.scalarmul_base(curve, ks) == got
 
 
@@ -105,8 +111,9 @@ def test_ct_whole_wavefronts_of_one_scalar(engine, oracle, curve):
     for v in (0, 1, order - 1, order, (1 << (8 * sb)) - 1, int("a5" * sb, 16) % order, 1 << (8 * sb - 3)):
         ks = _pack([v], sb) * 192
         want = oracle.base(curve, ks[:sb], threads=1)
-        got = engine.scalarmul_base(curve, ks, ct_scan=True)
-        assert got[0] == want[0] * 192 and got[1] == want[1] * 192
+        for lookup in LOOKUPS:
+            got = engine.scalarmul_base(curve, ks, **lookup)
+            assert got[0] == want[0] * 192 and got[1] == want[1] * 192
         wantv = oracle.var(curve, ks[:sb], pt1, threads=1)
         gotv = engine.scalarmul_var(curve, ks, pt1 * 192, ct_scan=True)
         assert gotv[0] == wantv[0] * 192 and gotv[1] == wantv[1] * 192
@@ -122,8 +129,9 @@ def test_ct_golden_vectors(engine):
         vec = kats[curve]
         ks = _pack([int(v["k"], 16) if isinstance(v["k"], str) else int(v["k"]) for v in vec], sb)
         want = b"".join(int(v["x"], 16).to_bytes(fb, "big") + int(v["y"], 16).to_bytes(fb, "big") for v in vec)
-        got = engine.scalarmul_base(curve, ks, ct_scan=True)
-        assert got[0] == want and set(got[1]) == {0}
+        for lookup in LOOKUPS:
+            got = engine.scalarmul_base(curve, ks, **lookup)
+            assert got[0] == want and set(got[1]) == {0}
         g = int(params[curve]["gx"], 16).to_bytes(fb, "big") + int(params[curve]["gy"], 16).to_bytes(fb, "big")
         got = engine.scalarmul_var(curve, ks, g * len(vec), ct_scan=True)
         assert got[0] == want and set(got[1]) == {0}
@@ -222,8 +230,9 @@ def test_ct_ragged_batches(engine, oracle, curve):
     for n in (1, 63, 64, 65, 255, 257, 1025):
         ks = W.random_scalars(curve, n, seed=950 + n).tobytes()
         want = oracle.base(curve, ks, threads=16)
-        got = engine.scalarmul_base(curve, ks, ct_scan=True)
-        assert got[0] == want[0] and got[1] == want[1]
+        for lookup in LOOKUPS:
+            got = engine.scalarmul_base(curve, ks, **lookup)
+            assert got[0] == want[0] and got[1] == want[1]
         pts = want[0] if curve != "ed25519" else _bases(oracle, curve, n, seed=3)
         ks2 = W.random_scalars(curve, n, seed=960 + n).tobytes()
         wantv = oracle.var(curve, ks2, pts, threads=16)
@@ -261,12 +270,14 @@ def test_ct_full_size_batches_match_the_default_kernels(engine, oracle, curve, l
     n = 1 << log2n
     dev = torch.device("cuda:0")
     ks = torch.from_numpy(W.random_scalars(curve, n, seed=971)).to(dev)
-    engine.prepare(curve, base=True, ct=True)
+    engine.prepare(curve, base=True, ct=True, ct_gather=True)
     engine.reserve(curve, n, var=True, ct=True)
     ob, fl_b = engine.scalarmul_base_t(curve, ks)
     oc, fl_c = engine.scalarmul_base_t(curve, ks, ct_scan=True)
+    og, fl_g = engine.scalarmul_base_t(curve, ks, ct_gather=True)
     torch.cuda.synchronize()
     assert torch.equal(ob, oc) and torch.equal(fl_b, fl_c)
+    assert torch.equal(ob, og) and torch.equal(fl_b, fl_g)
     sample = np.arange(0, n, n // 257)
     kb = ks.cpu().numpy().reshape(n, sb)[sample].tobytes()
     want = oracle.base(curve, kb, threads=16)
