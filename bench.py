@@ -142,76 +142,105 @@ VARIANT_MULT = {("bls12_381_g1_var_2^20", "glv"): _var_unsat(14, 14, 32, 1, 570,
 # 16-byte-per-lane reads on gfx950, plus WRITE_SIZE, summed over the kernels of one step.  Counters
 # cannot be read from inside this process, so `roofline.traffic` is loaded from the committed summary
 # of this very workload (named in traffic_detail.source); null when that file is absent.
-PROFILE_ROUND = "r02"
-# kernels of one step per workload op: substrings of the kernel names in the summary
+PROFILE_ROUNDS = ("r03", "r02")  # newest summary of the workload that exists
+# kernels of one step per (op, variant): for each, substrings of the kernel name in the summary, newest spelling first
+# (round 3 added the window width and the secret-scalar flag to the ladder's template arguments)
 STEP_KERNELS = {
     # variable base: the affine-table ladder, the generic ladder as its fix-up pass (reads the flags, redoes
     # marked units: none in these workloads), the normalisation
-    ("var", "default"): ["k_scalarmul_coz_unsat<eccx::{U}, eccx::NoGlv, false, false>", "k_scalarmul_var_unsat<eccx::{U}, false>",
-                         "k_batch_to_affine_unsat<eccx::{U}, 1,"],
-    ("var", "glv"): ["k_scalarmul_coz_unsat<eccx::{U}, eccx::BLS12_381_GLV, true, false>", "k_batch_to_affine_unsat<eccx::{U}, 1,"],
-    ("var", "mirror"): ["k_scalarmul_var_mirror_unsat<eccx::{U}>", "k_batch_to_affine<eccx::{S}, 0,"],
-    ("var", "ct"): ["k_scalarmul_var_mirror_unsat<eccx::{U}>", "k_batch_to_affine<eccx::{S}, 0,"],
-    ("dsm", "default"): ["k_scalarmul_coz_unsat<eccx::{U}, eccx::NoGlv, false, true>", "k_scalarmul_var_unsat<eccx::{U}, true>",
-                         "k_batch_to_affine_unsat<eccx::{U}, 1,"],
-    ("base", "default"): ["k_scalarmul_base_unsat<eccx::{U}>", "k_batch_to_affine_unsat<eccx::{U}, 1,"],
-    ("x25519", "default"): ["k_x25519_ladder_unsat<eccx::ED25519U>", "k_batch_to_affine_unsat<eccx::ED25519U, 3,"],
+    ("var", "default"): [["k_scalarmul_coz_unsat<eccx::{U}, eccx::{G}, false, false, 5, false>", "k_scalarmul_coz_unsat<eccx::{U}, eccx::{G}, false, false>"],
+                         ["k_scalarmul_var_unsat<eccx::{U}, false>"], ["k_batch_to_affine_unsat<eccx::{U}, 1,"]],
+    ("var", "glv"): [["k_scalarmul_coz_unsat<eccx::{U}, eccx::{G}, true, false, 5, false>", "k_scalarmul_coz_unsat<eccx::{U}, eccx::{G}, true, false>"],
+                     ["k_scalarmul_var_unsat<eccx::{U}, false>"], ["k_batch_to_affine_unsat<eccx::{U}, 1,"]],
+    ("var", "mirror"): [["k_scalarmul_var_mirror_unsat<eccx::{U}>"], ["k_batch_to_affine<eccx::{S}, 0,"]],
+    # secret scalars: the scanning affine-table ladder, the normalisation, the mirror ladder as fix-up pass
+    ("var", "ct"): [["k_scalarmul_coz_unsat<eccx::{U}, eccx::NoGlv, false, false, 4, true>"], ["k_batch_to_affine_unsat<eccx::{U}, 1,"],
+                    ["k_scalarmul_var_mirror_unsat<eccx::{U}>"]],
+    ("dsm", "default"): [["k_scalarmul_coz_unsat<eccx::{U}, eccx::NoGlv, false, true, 5, false>", "k_scalarmul_coz_unsat<eccx::{U}, eccx::NoGlv, false, true>"],
+                         ["k_scalarmul_var_unsat<eccx::{U}, true>"], ["k_batch_to_affine_unsat<eccx::{U}, 1,"]],
+    ("base", "default"): [["k_scalarmul_base_unsat<eccx::{U}>"], ["k_batch_to_affine_unsat<eccx::{U}, 1,"]],
+    ("base", "ct"): [["k_scalarmul_base_ct<eccx::{U}, false>"], ["k_batch_to_affine_unsat<eccx::{U}, 1,"]],
+    ("base", "ctg"): [["k_scalarmul_base_ct<eccx::{U}, true>"], ["k_batch_to_affine_unsat<eccx::{U}, 1,"]],
+    ("x25519", "default"): [["k_x25519_ladder_unsat<eccx::ED25519U>"], ["k_batch_to_affine_unsat<eccx::ED25519U, 3,"]],
 }
 ED_STEP_KERNELS = {
-    ("var", "default"): ["k_ed_scalarmul_var_unsat<eccx::ED25519U, false>", "k_batch_to_affine_unsat<eccx::ED25519U, 2,"],
-    ("dsm", "default"): ["k_ed_scalarmul_var_unsat<eccx::ED25519U, true>", "k_batch_to_affine_unsat<eccx::ED25519U, 2,"],
-    ("base", "default"): ["k_ed_scalarmul_base_unsat<eccx::ED25519U>", "k_batch_to_affine_unsat<eccx::ED25519U, 2,"],
-    ("base", "lds"): ["k_ed_scalarmul_base_lds6<eccx::ED25519U>", "k_batch_to_affine_unsat<eccx::ED25519U, 2,"],
+    ("var", "default"): [["k_ed_scalarmul_var_unsat<eccx::ED25519U, false>"], ["k_batch_to_affine_unsat<eccx::ED25519U, 2,"]],
+    ("dsm", "default"): [["k_ed_scalarmul_var_unsat<eccx::ED25519U, true>"], ["k_batch_to_affine_unsat<eccx::ED25519U, 2,"]],
+    ("base", "default"): [["k_ed_scalarmul_base_unsat<eccx::ED25519U>"], ["k_batch_to_affine_unsat<eccx::ED25519U, 2,"]],
+    ("base", "lds"): [["k_ed_scalarmul_base_lds6<eccx::ED25519U>"], ["k_batch_to_affine_unsat<eccx::ED25519U, 2,"]],
+    ("base", "ct"): [["k_ed_scalarmul_base_ct<eccx::ED25519U, false>"], ["k_batch_to_affine_unsat<eccx::ED25519U, 2,"]],
+    ("base", "ctg"): [["k_ed_scalarmul_base_ct<eccx::ED25519U, true>"], ["k_batch_to_affine_unsat<eccx::ED25519U, 2,"]],
 }
-# bls12_381_g1 variable base: the same three kernels, the ladder instantiated with the curve's endomorphism constants
-BLS_STEP_KERNELS = {
-    ("var", "default"): ["k_scalarmul_coz_unsat<eccx::BLS12_381U, eccx::BLS12_381_GLV, false, false>",
-                         "k_scalarmul_var_unsat<eccx::BLS12_381U, false>", "k_batch_to_affine_unsat<eccx::BLS12_381U, 1,"],
-    ("var", "glv"): ["k_scalarmul_coz_unsat<eccx::BLS12_381U, eccx::BLS12_381_GLV, true, false>",
-                     "k_scalarmul_var_unsat<eccx::BLS12_381U, false>", "k_batch_to_affine_unsat<eccx::BLS12_381U, 1,"],
-}
-CURVE_STRUCTS = {"p256r1": ("P256", "P256U"), "p384r1": ("P384", "P384U"), "p521r1": ("P521", "P521U"),
-                 "bls12_381_g1": ("BLS12_381", "BLS12_381U"), "ed25519": ("ED25519", "ED25519U")}
+# (S, U, G): saturated struct, unsaturated struct, the GLV argument the default ladder is instantiated with
+CURVE_STRUCTS = {"p256r1": ("P256", "P256U", "NoGlv"), "p384r1": ("P384", "P384U", "NoGlv"), "p521r1": ("P521", "P521U", "NoGlv"),
+                 "bls12_381_g1": ("BLS12_381", "BLS12_381U", "BLS12_381_GLV"), "ed25519": ("ED25519", "ED25519U", "NoGlv")}
 
 
 def profile_path(workload, variant):
-    tag = PROFILE_ROUND + "_" + workload.replace("^", "")
-    if variant != "default":
-        tag += "_" + variant
-    return os.path.join("profiles", tag + ".json")
+    """The committed rocprofv3 summary of this workload and variant: the newest round that has one."""
+    for rnd in PROFILE_ROUNDS:
+        tag = rnd + "_" + workload.replace("^", "")
+        if variant != "default":
+            tag += "_" + variant
+        rel = os.path.join("profiles", tag + ".json")
+        if os.path.exists(os.path.join(ROOT, rel)):
+            return rel
+    return None
+
+
+def _step_entries(workload, curve, op, variant):
+    """(summary path, [(pmc key, counters)] for the kernels of one step) or (None, None)"""
+    rel = profile_path(workload, variant)
+    table = ED_STEP_KERNELS if curve == "ed25519" and op != "x25519" else STEP_KERNELS
+    pats = table.get((op, variant))
+    if rel is None or not pats:
+        return None, None
+    with open(os.path.join(ROOT, rel)) as f:
+        prof = json.load(f)
+    S, U, G = CURVE_STRUCTS[curve]
+    found = []
+    for alts in pats:
+        best = None
+        for alt in alts:
+            pat = alt.format(S=S, U=U, G=G)
+            for key, v in prof.get("pmc", {}).items():
+                if pat in key and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                    # the (kernel, grid) entry with the most dispatches: the timed launches
+                    rank = (v["FETCH_SIZE"]["dispatches"], v["hbm_read_bytes_per_dispatch_raw"])
+                    if best is None or rank > best[0]:
+                        best = (rank, key, v)
+            if best is not None:
+                break
+        if best is None:
+            return rel, None
+        found.append((best[1], best[2]))
+    return rel, found
 
 
 def measured_traffic(workload, curve, op, variant):
     """HBM bytes of one step from the committed rocprofv3 PMC summary of this workload: for each
-    kernel of the step, the (kernel, grid) entry with the most dispatches (the timed launches),
-    FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE.  None if there is no summary."""
-    rel = profile_path(workload, variant)
-    path = os.path.join(ROOT, rel)
-    table = ED_STEP_KERNELS if curve == "ed25519" and op != "x25519" else STEP_KERNELS
-    pats = table.get((op, variant))
-    if curve == "bls12_381_g1" and (op, variant) in BLS_STEP_KERNELS:
-        pats = BLS_STEP_KERNELS[(op, variant)]
-    if not os.path.exists(path) or not pats:
+    kernel of the step FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE.  None if there is no summary."""
+    rel, found = _step_entries(workload, curve, op, variant)
+    if not found:
         return None
-    with open(path) as f:
-        prof = json.load(f)
-    S, U = CURVE_STRUCTS[curve]
-    fetch = write = 0.0
-    used = []
-    for pat in pats:
-        pat = pat.format(S=S, U=U)
-        best = None
-        for key, v in prof.get("pmc", {}).items():
-            if pat in key and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-                rank = (v["FETCH_SIZE"]["dispatches"], v["hbm_read_bytes_per_dispatch_raw"])
-                if best is None or rank > best[0]:
-                    best = (rank, key, v)
-        if best is None:
-            return None
-        fetch += best[2]["hbm_read_bytes_per_dispatch_raw"]
-        write += best[2]["hbm_write_bytes_per_dispatch"]
-        used.append(best[1])
-    return {"bytes": int(2 * fetch + write), "fetch_raw": int(fetch), "write": int(write), "source": rel, "kernels": used}
+    fetch = sum(v["hbm_read_bytes_per_dispatch_raw"] for _, v in found)
+    write = sum(v["hbm_write_bytes_per_dispatch"] for _, v in found)
+    return {"bytes": int(2 * fetch + write), "fetch_raw": int(fetch), "write": int(write), "source": rel, "kernels": [k for k, _ in found]}
+
+
+def measured_clock(workload, curve, op, variant):
+    """Effective shader clock of the step's dominant kernel and its cycles per vector instruction, from the same
+    summary (tools/prof_summary.py: GRBM_GUI_ACTIVE / 8 / duration of the same dispatch).  None before round 3's
+    summaries exist for the workload."""
+    rel, found = _step_entries(workload, curve, op, variant)
+    if not found:
+        return None
+    key, v = found[0]
+    clk = v.get("effective_clock_ghz")
+    if not clk:
+        return None
+    return {"hz": clk["median"] * 1e9, "source": rel, "kernel": key, "how": clk.get("how"),
+            "cycles_per_valu_inst": (v.get("cycles_per_valu_inst") or {}).get("median")}
 
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -222,7 +251,7 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 CYC_MAD = 4.8
 CYC_PAIR = 8.62
 SIMDS = 256 * 4
-CLOCK_HZ = 2.4e9
+CLOCK_HZ_NOMINAL = 2.4e9  # only where no summary with GRBM_GUI_ACTIVE exists for the workload: the chip holds about 2.25 GHz on these kernels
 
 
 def _cpu_model():
@@ -259,6 +288,45 @@ def _usable_cores():
     except (OSError, ValueError):
         pass
     return n
+
+
+def host_path(eng, curve, op, n, ks, pts, dev_out, opts_bits):
+    """The same batch through the HOST-buffer entry point (what a caller without device buffers -- the Rust crate --
+    uses): pageable host memory in, pageable host memory out, PCIe copies and the final synchronisation included.
+    Never part of `value` (reported separately).  The first call sizes the context's device-side
+    buffers; the best of the next three is reported, and its output must equal the device-resident run's."""
+    import ctypes
+
+    import numpy as np
+
+    import eccoxide_amd as E
+
+    cid, fb, sb = E.curve_id(curve), E.field_bytes(curve), E.scalar_bytes(curve)
+    lib, ctx = eng._lib, eng._ctx
+    hk = np.ascontiguousarray(ks.cpu().numpy())
+    hp = np.ascontiguousarray(pts.cpu().numpy()) if op == "var" else None
+    ho = np.empty((n, 2 * fb), dtype=np.uint8)
+    hf = np.empty((n,), dtype=np.uint8)
+    eng.reserve(curve, n, var=False, host=True)
+
+    def call():
+        t = time.perf_counter()
+        if op == "var":
+            rc = lib.eccx_scalarmul_var(ctx, cid, n, hk.ctypes.data, hp.ctypes.data, ho.ctypes.data, hf.ctypes.data, None, opts_bits)
+        else:
+            rc = lib.eccx_scalarmul_base(ctx, cid, n, hk.ctypes.data, ho.ctypes.data, hf.ctypes.data, None, opts_bits)
+        dt = time.perf_counter() - t
+        eng._check(rc)
+        return dt
+
+    call()
+    best = min(call() for _ in range(3))
+    same = bool((ho == dev_out.cpu().numpy()).all())
+    pcie = n * (sb + (2 * fb if op == "var" else 0)) + n * (2 * fb + 1)
+    return {"ms": best * 1e3, "units_per_s": n / best, "pcie_bytes": pcie, "matches_device_run": same,
+            "entry_point": "eccx_scalarmul_var" if op == "var" else "eccx_scalarmul_base",
+            "note": "host-buffer call on the same batch: pageable host memory, H2D + kernels + D2H + synchronisation; "
+                    "not part of value (tools/hostbench: the same measurement from C, profiles/r03_hostbench.jsonl)"}
 
 
 def cpu_baseline(ora, curve, op, args, n, ks, ks2, pts):
@@ -316,6 +384,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="p256r1_var_2^20", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the host-buffer (PCIe-inclusive) measurement")
     ap.add_argument("--cpu-sample", type=int, default=1 << 17)
     ap.add_argument("--variant", default="default", choices=["default", "mirror", "lds", "l2", "ct", "ctg", "glv"],
                     help="default: fast kernels; mirror: reference-mirroring kernels; "
@@ -453,6 +522,9 @@ def main():
     # from its seeds.
     parity = None
     cpu = None
+    host = None
+    opts_bits = (E.engine.MIRROR_REFERENCE if mirror else 0) | (E.engine.CT_SCAN if ct else 0) | (E.engine.CT_GATHER if ctg else 0) | \
+                (E.engine.ASSUME_SUBGROUP if glv else 0) | ({"lds": E.engine.TABLE_IN_LDS, "l2": E.engine.TABLE_IN_L2}.get(args.variant, 0))
     if rank == 0:
         from tests import oracle_lib
 
@@ -507,6 +579,8 @@ def main():
             parity = parity and (g_out[pidx].cpu().numpy().tobytes() == pw_out) and (g_flags[pidx].cpu().numpy().tobytes() == pw_inf)
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(ora, curve, op, args, n, ks, ks2, pts)
+        if world == 1 and not args.no_host_path and op in ("var", "base"):
+            host = host_path(eng, curve, op, n, ks, pts, out, opts_bits)
 
     if rank == 0:
         total_units = n * world * args.steps
@@ -515,7 +589,9 @@ def main():
         # time the SIMDs must spend issuing the multiplier instructions of this batch (one
         # instruction serves the 64 units of a wave) against the kernel time
         issue_cycles = mult["mad"] * CYC_MAD + mult["pair"] * CYC_PAIR
-        valu_frac = (n / 64) * issue_cycles / (kernel_ms * 1e-3 * SIMDS * CLOCK_HZ)
+        clock = measured_clock(args.workload, curve, op, args.variant)
+        clock_hz = clock["hz"] if clock else CLOCK_HZ_NOMINAL
+        valu_frac = (n / 64) * issue_cycles / (kernel_ms * 1e-3 * SIMDS * clock_hz)
         mul_rate = (mult["mad"] + mult["pair"]) * n / (kernel_ms * 1e-3)
         traffic = measured_traffic(args.workload, curve, op, args.variant)
         line = {
@@ -550,9 +626,11 @@ def main():
                      "frac": valu_frac,
                      "mads_per_unit": mult["mad"], "mad_addc_pairs_per_unit": mult["pair"],
                      "issue_cycles_per_wave": issue_cycles,
+                     "clock": clock if clock else {"hz": CLOCK_HZ_NOMINAL, "source": "nominal (no rocprofv3 summary with GRBM_GUI_ACTIVE for this workload)"},
                      "note": "frac = share of SIMD issue time spent on multiplier instructions at the "
                              "measured issue cost (4.8 cycles per mad, 8.62 per mad+addc pair)"},
             "cpu_baseline": cpu,
+            "host_path": host,
             "parity_sample_ok": parity,
         }
         if force_dist:

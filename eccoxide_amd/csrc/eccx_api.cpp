@@ -61,6 +61,14 @@ struct eccx_ctx {
   size_t jac_words = 0;
   std::mutex scratch_mu;
   size_t table_bytes = 0;  // fixed-base tables owned by the context (eccx_device_bytes)
+  // device-side I/O buffers of the HOST-buffer entry points (grow-only, like the slabs; eccx_reserve with
+  // ECCX_PREP_HOST sizes them) and the events their chunked copies use: after warm-up a host-buffer call
+  // allocates and frees nothing
+  static constexpr int NIO = 7;
+  uint8_t* io[NIO] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t io_cap[NIO] = {0, 0, 0, 0, 0, 0, 0};
+  static constexpr int NEV = 10;
+  hipEvent_t evs[NEV] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   std::mutex err_mu;       // err is written by whichever host thread's call failed last
   std::string err;
   void set_err(std::string m) {
@@ -124,6 +132,24 @@ int ensure_scratch(eccx_ctx* ctx, int row_words, int grid) {
 int ensure_rows(eccx_ctx* ctx, const CurveOps* ops, size_t n) {
   std::lock_guard<std::mutex> g(ctx->scratch_mu);
   return ensure_buffer(ctx, &ctx->jac, &ctx->jac_words, n * (size_t)ops->info.jac_words);
+}
+
+// I/O slots of the host-buffer entry points
+enum { IO_K = 0, IO_P = 1, IO_O = 2, IO_F = 3, IO_J = 4, IO_A = 5, IO_B = 6 };
+int ensure_io(eccx_ctx* ctx, int slot, size_t bytes, uint8_t** out) {
+  std::lock_guard<std::mutex> g(ctx->scratch_mu);
+  if (bytes > ctx->io_cap[slot]) {
+    if (ctx->io[slot]) {
+      HIP_TRY(ctx, hipDeviceSynchronize());
+      HIP_TRY(ctx, hipFree(ctx->io[slot]));
+      ctx->io[slot] = nullptr;
+      ctx->io_cap[slot] = 0;
+    }
+    HIP_TRY(ctx, hipMalloc(&ctx->io[slot], bytes));
+    ctx->io_cap[slot] = bytes;
+  }
+  *out = ctx->io[slot];
+  return ECCX_OK;
 }
 
 int norm_grid(const eccx_ctx* ctx, size_t n) {
@@ -416,7 +442,9 @@ uint32_t kopts_of(uint32_t opts) { return (opts & ECCX_VALIDATE_POINTS) ? K_VALI
 
 size_t proj_bytes(const CurveOps* ops) { return (size_t)(ops->info.edwards ? 4 : 3) * ops->info.fb; }
 
-// host-buffer wrapper shared by var / base
+// host-buffer wrapper shared by var / base.  Device-side copies of the caller's buffers live in the context's
+// I/O slots (grow-only: nothing is allocated or freed once a batch of this size has been seen, or after
+// eccx_reserve(..., ECCX_PREP_HOST)), the events come from the context's pool.
 int run_host(eccx_ctx* ctx, int curve, bool base, size_t n, const uint8_t* scalars, const uint8_t* points,
              uint8_t* out, uint8_t* flags, uint8_t* proj, uint32_t opts) {
   const CurveOps* ops = ops_of(curve);
@@ -427,28 +455,12 @@ int run_host(eccx_ctx* ctx, int curve, bool base, size_t n, const uint8_t* scala
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   size_t sb = ops->info.sb, pb = 2 * (size_t)ops->info.fb;
   uint8_t *d_k = nullptr, *d_p = nullptr, *d_o = nullptr, *d_f = nullptr, *d_j = nullptr;
-  int rc = ECCX_OK;
-  auto cleanup = [&]() {
-    if (d_k) (void)hipFree(d_k);
-    if (d_p) (void)hipFree(d_p);
-    if (d_o) (void)hipFree(d_o);
-    if (d_f) (void)hipFree(d_f);
-    if (d_j) (void)hipFree(d_j);
-  };
-#define TRY_(call)                                  \
-  do {                                              \
-    hipError_t e_ = (call);                         \
-    if (e_ != hipSuccess) {                         \
-      ctx->set_err(std::string(#call) + ": " + hipGetErrorString(e_)); \
-      cleanup();                                    \
-      return e_ == hipErrorOutOfMemory ? ECCX_ERR_NOMEM : ECCX_ERR_HIP; \
-    }                                               \
-  } while (0)
-  TRY_(hipMalloc(&d_k, n * sb));
-  TRY_(hipMalloc(&d_o, n * pb));
-  TRY_(hipMalloc(&d_f, n));
-  if (!base) TRY_(hipMalloc(&d_p, n * pb));
-  if (proj) TRY_(hipMalloc(&d_j, n * proj_bytes(ops)));
+  int rc = ensure_io(ctx, IO_K, n * sb, &d_k);
+  if (!rc) rc = ensure_io(ctx, IO_O, n * pb, &d_o);
+  if (!rc) rc = ensure_io(ctx, IO_F, n, &d_f);
+  if (!rc && !base) rc = ensure_io(ctx, IO_P, n * pb, &d_p);
+  if (!rc && proj) rc = ensure_io(ctx, IO_J, n * proj_bytes(ops), &d_j);
+  if (rc) return rc;
   // Large batches go through in chunks so that the PCIe copies of chunk i+1 (in) and i-1 (out) run
   // beside the kernels of chunk i: three streams, events between them.  The host buffers are
   // pageable, so each copy call returns when its data has been staged; the kernels it overlaps
@@ -456,40 +468,30 @@ int run_host(eccx_ctx* ctx, int curve, bool base, size_t n, const uint8_t* scala
   // (variable base only: measured 20.8 -> 19.3 ms for 2^20 p256 units; the fixed-base kernels are
   // shorter than their copies and lose to the per-chunk launch costs: 3.4 -> 4.5 ms)
   const size_t nchunks = (!proj && !base && n >= ((size_t)1 << 17)) ? 4 : 1;
+  static_assert(2 * 4 <= eccx_ctx::NEV, "two events per chunk");
   const size_t step = ((n + nchunks - 1) / nchunks + 4095) / 4096 * 4096;
   // a single chunk keeps everything on the compute stream (crossing streams costs ~1 ms of idle gaps)
   hipStream_t s_in = nchunks > 1 ? ctx->in_stream : ctx->stream;
   hipStream_t s_out = nchunks > 1 ? ctx->out_stream : ctx->stream;
-  std::vector<hipEvent_t> evs;
-  auto new_event = [&](hipEvent_t* e) {
-    hipError_t r = hipEventCreateWithFlags(e, hipEventDisableTiming);
-    if (r == hipSuccess) evs.push_back(*e);
-    return r;
-  };
-  auto drop_events = [&]() {
-    for (auto e : evs) (void)hipEventDestroy(e);
-    evs.clear();
-  };
-  auto cleanup_all = [&]() {
+  int next_ev = 0;
+  auto settle = [&]() {  // on an error path: nothing of this call may still be running when the caller's buffers go away
     (void)hipStreamSynchronize(s_in);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamSynchronize(s_out);
-    drop_events();
-    cleanup();
   };
 #define TRY2_(call)                                 \
   do {                                              \
     hipError_t e_ = (call);                         \
     if (e_ != hipSuccess) {                         \
       ctx->set_err(std::string(#call) + ": " + hipGetErrorString(e_)); \
-      cleanup_all();                                \
+      settle();                                     \
       return e_ == hipErrorOutOfMemory ? ECCX_ERR_NOMEM : ECCX_ERR_HIP; \
     }                                               \
   } while (0)
   hipEvent_t prev_done = nullptr;
   size_t prev_lo = 0, prev_cnt = 0;
   auto copy_out = [&](size_t lo, size_t cnt, hipEvent_t done) -> hipError_t {
-    hipError_t r = hipStreamWaitEvent(s_out, done, 0);
+    hipError_t r = s_out == ctx->stream ? hipSuccess : hipStreamWaitEvent(s_out, done, 0);
     if (r == hipSuccess) r = hipMemcpyAsync(out + lo * pb, d_o + lo * pb, cnt * pb, hipMemcpyDeviceToHost, s_out);
     if (r == hipSuccess) r = hipMemcpyAsync(flags + lo, d_f + lo, cnt, hipMemcpyDeviceToHost, s_out);
     return r;
@@ -498,29 +500,27 @@ int run_host(eccx_ctx* ctx, int curve, bool base, size_t n, const uint8_t* scala
     const size_t cnt = std::min(step, n - lo);
     TRY2_(hipMemcpyAsync(d_k + lo * sb, scalars + lo * sb, cnt * sb, hipMemcpyHostToDevice, s_in));
     if (!base) TRY2_(hipMemcpyAsync(d_p + lo * pb, points + lo * pb, cnt * pb, hipMemcpyHostToDevice, s_in));
-    hipEvent_t in_ready, done;
-    TRY2_(new_event(&in_ready));
-    TRY2_(hipEventRecord(in_ready, s_in));
-    TRY2_(hipStreamWaitEvent(ctx->stream, in_ready, 0));
+    hipEvent_t done = nullptr;
+    if (nchunks > 1) {
+      hipEvent_t in_ready = ctx->evs[next_ev++];
+      done = ctx->evs[next_ev++];
+      TRY2_(hipEventRecord(in_ready, s_in));
+      TRY2_(hipStreamWaitEvent(ctx->stream, in_ready, 0));
+    }
     if (base) rc = eccx_scalarmul_base_dev(ctx, curve, cnt, d_k + lo * sb, d_o + lo * pb, d_f + lo, d_j, opts, ctx->stream);
     else rc = eccx_scalarmul_var_dev(ctx, curve, cnt, d_k + lo * sb, d_p + lo * pb, d_o + lo * pb, d_f + lo, d_j, opts, ctx->stream);
-    if (rc) { cleanup_all(); return rc; }
-    TRY2_(new_event(&done));
-    TRY2_(hipEventRecord(done, ctx->stream));
-    if (prev_done) TRY2_(copy_out(prev_lo, prev_cnt, prev_done));
+    if (rc) { settle(); return rc; }
+    if (nchunks > 1) {
+      TRY2_(hipEventRecord(done, ctx->stream));
+      if (prev_done) TRY2_(copy_out(prev_lo, prev_cnt, prev_done));
+    }
     prev_done = done; prev_lo = lo; prev_cnt = cnt;
   }
   TRY2_(copy_out(prev_lo, prev_cnt, prev_done));
-  if (proj) {
-    TRY2_(hipStreamWaitEvent(s_out, prev_done, 0));
-    TRY2_(hipMemcpyAsync(proj, d_j, n * proj_bytes(ops), hipMemcpyDeviceToHost, s_out));
-  }
+  if (proj) TRY2_(hipMemcpyAsync(proj, d_j, n * proj_bytes(ops), hipMemcpyDeviceToHost, s_out));  // single chunk: same stream
   TRY2_(hipStreamSynchronize(s_out));
-  TRY2_(hipStreamSynchronize(ctx->stream));
-  drop_events();
+  if (s_out != ctx->stream) TRY2_(hipStreamSynchronize(ctx->stream));
 #undef TRY2_
-#undef TRY_
-  cleanup();
   return ECCX_OK;
 }
 
@@ -580,6 +580,11 @@ int eccx_init(int device, eccx_ctx** out_ctx) {
     delete ctx;
     return ECCX_ERR_HIP;
   }
+  for (auto& e : ctx->evs)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+      eccx_shutdown(ctx);
+      return ECCX_ERR_HIP;
+    }
   *out_ctx = ctx;
   return ECCX_OK;
 }
@@ -600,6 +605,10 @@ void eccx_shutdown(eccx_ctx* ctx) {
     if (t) (void)hipFree(t);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->jac) (void)hipFree(ctx->jac);
+  for (auto& b : ctx->io)
+    if (b) (void)hipFree(b);
+  for (auto& e : ctx->evs)
+    if (e) (void)hipEventDestroy(e);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->in_stream) (void)hipStreamDestroy(ctx->in_stream);
   if (ctx->out_stream) (void)hipStreamDestroy(ctx->out_stream);
@@ -665,6 +674,18 @@ int eccx_reserve(eccx_ctx* ctx, int curve, size_t max_n, uint32_t what) {
       if (rc) return rc;
     }
   }
+  if (what & ECCX_PREP_HOST) {  // device-side copies of the host-buffer entry points' arguments
+    const size_t pb = 2 * (size_t)ops->info.fb, sbytes = (size_t)ops->info.sb;
+    uint8_t* dummy = nullptr;
+    rc = ensure_io(ctx, IO_K, max_n * std::max(pb, sbytes), &dummy);   // scalars; first operand of the group law
+    if (!rc) rc = ensure_io(ctx, IO_P, max_n * pb, &dummy);
+    if (!rc) rc = ensure_io(ctx, IO_O, max_n * pb, &dummy);
+    if (!rc) rc = ensure_io(ctx, IO_F, max_n, &dummy);
+    if (!rc) rc = ensure_io(ctx, IO_J, max_n * sbytes, &dummy);            // second scalar of the verify shape
+    if (!rc) rc = ensure_io(ctx, IO_A, max_n, &dummy);
+    if (!rc) rc = ensure_io(ctx, IO_B, max_n, &dummy);
+    if (rc) return rc;
+  }
   if ((what & ECCX_PREP_CT) && ops->var_ct) {  // secret scalars: the scanning affine-table ladder + its fix-up
     rc = ensure_scratch(ctx, ops->coz_row_words, ops->var_ct_grid(ctx->cus, max_n));
     if (rc) return rc;
@@ -687,7 +708,9 @@ size_t eccx_device_bytes(const eccx_ctx* ctx) {
   eccx_ctx* c = const_cast<eccx_ctx*>(ctx);
   std::lock_guard<std::mutex> g1(c->comb_mu);
   std::lock_guard<std::mutex> g2(c->scratch_mu);
-  return c->table_bytes + (c->scratch_words + c->jac_words) * sizeof(uint32_t);
+  size_t io = 0;
+  for (size_t b : c->io_cap) io += b;
+  return c->table_bytes + (c->scratch_words + c->jac_words) * sizeof(uint32_t) + io;
 }
 
 int eccx_scalarmul_var_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_scalars, const void* d_points,
@@ -834,20 +857,20 @@ int eccx_point_add(eccx_ctx* ctx, int curve, size_t n, const uint8_t* a, const u
   if (!a || !b || !out || !flags) return arg_err(ctx, "null buffer");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const size_t pb = 2 * (size_t)ops->info.fb;
-  DevMem mem;
   uint8_t *d_a = nullptr, *d_b = nullptr, *d_ai = nullptr, *d_bi = nullptr, *d_out = nullptr, *d_flags = nullptr;
-  HIP_TRY(ctx, mem.alloc(&d_a, n * pb));
-  HIP_TRY(ctx, mem.alloc(&d_b, n * pb));
-  if (a_inf) HIP_TRY(ctx, mem.alloc(&d_ai, n));
-  if (b_inf) HIP_TRY(ctx, mem.alloc(&d_bi, n));
-  HIP_TRY(ctx, mem.alloc(&d_out, n * pb));
-  HIP_TRY(ctx, mem.alloc(&d_flags, n));
+  int rc = ensure_io(ctx, IO_K, n * pb, &d_a);
+  if (!rc) rc = ensure_io(ctx, IO_P, n * pb, &d_b);
+  if (!rc && a_inf) rc = ensure_io(ctx, IO_A, n, &d_ai);
+  if (!rc && b_inf) rc = ensure_io(ctx, IO_B, n, &d_bi);
+  if (!rc) rc = ensure_io(ctx, IO_O, n * pb, &d_out);
+  if (!rc) rc = ensure_io(ctx, IO_F, n, &d_flags);
+  if (rc) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(d_a, a, n * pb, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(d_b, b, n * pb, hipMemcpyHostToDevice, ctx->stream));
   if (a_inf) HIP_TRY(ctx, hipMemcpyAsync(d_ai, a_inf, n, hipMemcpyHostToDevice, ctx->stream));
   if (b_inf) HIP_TRY(ctx, hipMemcpyAsync(d_bi, b_inf, n, hipMemcpyHostToDevice, ctx->stream));
-  int rc = eccx_point_add_dev(ctx, curve, n, d_a, d_ai, d_b, d_bi, d_out, d_flags, opts, ctx->stream);
-  if (rc) return rc;
+  rc = eccx_point_add_dev(ctx, curve, n, d_a, d_ai, d_b, d_bi, d_out, d_flags, opts, ctx->stream);
+  if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
   HIP_TRY(ctx, hipMemcpyAsync(out, d_out, n * pb, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(flags, d_flags, n, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -910,14 +933,14 @@ int eccx_point_decompress(eccx_ctx* ctx, int curve, size_t n, const uint8_t* enc
   if (!enc || !out || !flags) return arg_err(ctx, "null buffer");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const size_t pb = 2 * (size_t)ops->info.fb, eb = (opts & ECCX_UNCOMPRESSED) ? pb : (size_t)ops->enc_bytes;
-  DevMem mem;
   uint8_t *d_enc = nullptr, *d_out = nullptr, *d_flags = nullptr;
-  HIP_TRY(ctx, mem.alloc(&d_enc, n * eb));
-  HIP_TRY(ctx, mem.alloc(&d_out, n * pb));
-  HIP_TRY(ctx, mem.alloc(&d_flags, n));
-  HIP_TRY(ctx, hipMemcpyAsync(d_enc, enc, n * eb, hipMemcpyHostToDevice, ctx->stream));
-  int rc = eccx_point_decompress_dev(ctx, curve, n, d_enc, d_out, d_flags, opts, ctx->stream);
+  int rc = ensure_io(ctx, IO_K, n * eb, &d_enc);
+  if (!rc) rc = ensure_io(ctx, IO_O, n * pb, &d_out);
+  if (!rc) rc = ensure_io(ctx, IO_F, n, &d_flags);
   if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(d_enc, enc, n * eb, hipMemcpyHostToDevice, ctx->stream));
+  rc = eccx_point_decompress_dev(ctx, curve, n, d_enc, d_out, d_flags, opts, ctx->stream);
+  if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
   HIP_TRY(ctx, hipMemcpyAsync(out, d_out, n * pb, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(flags, d_flags, n, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -933,15 +956,15 @@ int eccx_point_compress(eccx_ctx* ctx, int curve, size_t n, const uint8_t* xy, c
   if (!xy || !out) return arg_err(ctx, "null buffer");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const size_t pb = 2 * (size_t)ops->info.fb, eb = (opts & ECCX_UNCOMPRESSED) ? pb : (size_t)ops->enc_bytes;
-  DevMem mem;
   uint8_t *d_xy = nullptr, *d_inf = nullptr, *d_out = nullptr;
-  HIP_TRY(ctx, mem.alloc(&d_xy, n * pb));
-  if (inf) HIP_TRY(ctx, mem.alloc(&d_inf, n));
-  HIP_TRY(ctx, mem.alloc(&d_out, n * eb));
+  int rc = ensure_io(ctx, IO_P, n * pb, &d_xy);
+  if (!rc && inf) rc = ensure_io(ctx, IO_A, n, &d_inf);
+  if (!rc) rc = ensure_io(ctx, IO_O, n * eb, &d_out);
+  if (rc) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(d_xy, xy, n * pb, hipMemcpyHostToDevice, ctx->stream));
   if (inf) HIP_TRY(ctx, hipMemcpyAsync(d_inf, inf, n, hipMemcpyHostToDevice, ctx->stream));
-  int rc = eccx_point_compress_dev(ctx, curve, n, d_xy, d_inf, d_out, opts, ctx->stream);
-  if (rc) return rc;
+  rc = eccx_point_compress_dev(ctx, curve, n, d_xy, d_inf, d_out, opts, ctx->stream);
+  if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
   HIP_TRY(ctx, hipMemcpyAsync(out, d_out, n * eb, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return ECCX_OK;
@@ -1001,18 +1024,18 @@ int eccx_double_scalarmul(eccx_ctx* ctx, int curve, size_t n, const uint8_t* u1,
   if (!u1 || !u2 || !q || !out || !flags) return arg_err(ctx, "null buffer");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const size_t pb = 2 * (size_t)ops->info.fb, sb = (size_t)ops->info.sb;
-  DevMem mem;
   uint8_t *d_u1 = nullptr, *d_u2 = nullptr, *d_q = nullptr, *d_o = nullptr, *d_f = nullptr;
-  HIP_TRY(ctx, mem.alloc(&d_u1, n * sb));
-  HIP_TRY(ctx, mem.alloc(&d_u2, n * sb));
-  HIP_TRY(ctx, mem.alloc(&d_q, n * pb));
-  HIP_TRY(ctx, mem.alloc(&d_o, n * pb));
-  HIP_TRY(ctx, mem.alloc(&d_f, n));
+  int rc = ensure_io(ctx, IO_K, n * sb, &d_u2);
+  if (!rc) rc = ensure_io(ctx, IO_J, n * sb, &d_u1);
+  if (!rc) rc = ensure_io(ctx, IO_P, n * pb, &d_q);
+  if (!rc) rc = ensure_io(ctx, IO_O, n * pb, &d_o);
+  if (!rc) rc = ensure_io(ctx, IO_F, n, &d_f);
+  if (rc) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(d_u1, u1, n * sb, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(d_u2, u2, n * sb, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(d_q, q, n * pb, hipMemcpyHostToDevice, ctx->stream));
-  int rc = eccx_double_scalarmul_dev(ctx, curve, n, d_u1, d_u2, d_q, d_o, d_f, opts, ctx->stream);
-  if (rc) return rc;
+  rc = eccx_double_scalarmul_dev(ctx, curve, n, d_u1, d_u2, d_q, d_o, d_f, opts, ctx->stream);
+  if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
   HIP_TRY(ctx, hipMemcpyAsync(out, d_o, n * pb, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(flags, d_f, n, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1047,30 +1070,18 @@ int eccx_x25519(eccx_ctx* ctx, size_t n, const uint8_t* scalars, const uint8_t* 
   if (!scalars || !out || !flags) return arg_err(ctx, "null buffer");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   uint8_t *d_k = nullptr, *d_u = nullptr, *d_o = nullptr, *d_f = nullptr;
-  auto cleanup = [&]() {
-    if (d_k) (void)hipFree(d_k);
-    if (d_u) (void)hipFree(d_u);
-    if (d_o) (void)hipFree(d_o);
-    if (d_f) (void)hipFree(d_f);
-  };
-  auto fail = [&](hipError_t e, const char* what) {
-    ctx->set_err(std::string(what) + ": " + hipGetErrorString(e));
-    cleanup();
-    return e == hipErrorOutOfMemory ? ECCX_ERR_NOMEM : ECCX_ERR_HIP;
-  };
-  hipError_t e;
-  if ((e = hipMalloc(&d_k, n * 32)) != hipSuccess) return fail(e, "hipMalloc");
-  if ((e = hipMalloc(&d_o, n * 32)) != hipSuccess) return fail(e, "hipMalloc");
-  if ((e = hipMalloc(&d_f, n)) != hipSuccess) return fail(e, "hipMalloc");
-  if (u && (e = hipMalloc(&d_u, n * 32)) != hipSuccess) return fail(e, "hipMalloc");
-  if ((e = hipMemcpyAsync(d_k, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail(e, "hipMemcpyAsync");
-  if (u && (e = hipMemcpyAsync(d_u, u, n * 32, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail(e, "hipMemcpyAsync");
-  int rc = eccx_x25519_dev(ctx, n, d_k, d_u, d_o, d_f, opts, ctx->stream);
-  if (rc) { cleanup(); return rc; }
-  if ((e = hipMemcpyAsync(out, d_o, n * 32, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) return fail(e, "hipMemcpyAsync");
-  if ((e = hipMemcpyAsync(flags, d_f, n, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) return fail(e, "hipMemcpyAsync");
-  if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(e, "hipStreamSynchronize");
-  cleanup();
+  int rc = ensure_io(ctx, IO_K, n * 32, &d_k);
+  if (!rc) rc = ensure_io(ctx, IO_O, n * 32, &d_o);
+  if (!rc) rc = ensure_io(ctx, IO_F, n, &d_f);
+  if (!rc && u) rc = ensure_io(ctx, IO_P, n * 32, &d_u);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(d_k, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  if (u) HIP_TRY(ctx, hipMemcpyAsync(d_u, u, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  rc = eccx_x25519_dev(ctx, n, d_k, d_u, d_o, d_f, opts, ctx->stream);
+  if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+  HIP_TRY(ctx, hipMemcpyAsync(out, d_o, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(flags, d_f, n, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return ECCX_OK;
 }
 

@@ -206,14 +206,14 @@ ECCX_DEV void uxyzz_dbl_affine(UXyzz<CU>& r, const U<CU, 1, 3>& x, const U<CU, 1
 }
 
 // affine points as canonical big-endian bytes x | y -> table entries (x, y) in the field's working form,
-// `stride` words per entry (the padding words are zeroed); a zero record (the engine's encoding of
+// ct_entry_words() words per entry (the padding words are zeroed); a zero record (the engine's encoding of
 // infinity: the entry of a digit that cannot occur) stays zero
 template <class CU>
-__global__ void k_affine_to_cttable(size_t entries, const uint8_t* __restrict__ affine, uint32_t* __restrict__ table,
-                                    int stride) {
+__global__ void k_affine_to_cttable(size_t entries, const uint8_t* __restrict__ affine, uint32_t* __restrict__ table) {
   using CS = typename CU::Sat;
   constexpr int L = CS::L;
   constexpr int FB = CS::FB;
+  constexpr int EW = ct_entry_words<CU>();
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= entries) return;
   Fe<L> px, py;
@@ -221,8 +221,9 @@ __global__ void k_affine_to_cttable(size_t entries, const uint8_t* __restrict__ 
   fe_load_be<CS>(py, affine + i * (size_t)(2 * FB) + FB);
   const auto ux = u_to_mont<CU>(px);
   const auto uy = u_to_mont<CU>(py);
-  uint32_t* o = table + i * (size_t)stride;
-  for (int k = 0; k < stride; ++k) o[k] = k < CU::N ? ux.v[k] : (k < 2 * CU::N ? uy.v[k - CU::N] : 0u);
+  uint32_t* o = table + i * (size_t)EW;
+#pragma unroll
+  for (int k = 0; k < EW; ++k) o[k] = k < CU::N ? ux.v[k] : (k < 2 * CU::N ? uy.v[k - CU::N] : 0u);
 }
 
 // Fixed base, secret scalars (Point::mul_base, src/curve/fiat/curve_macros.rs:55-63 ->

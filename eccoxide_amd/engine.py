@@ -24,7 +24,7 @@ UNCOMPRESSED = 1 << 7
 CT_SCAN = 1 << 8
 ASSUME_SUBGROUP = 1 << 9
 CT_GATHER = 1 << 10
-PREP_VAR, PREP_BASE, PREP_BASE_LDS, PREP_MIRROR, PREP_CT, PREP_CT_GATHER = 1, 2, 4, 8, 16, 32
+PREP_VAR, PREP_BASE, PREP_BASE_LDS, PREP_MIRROR, PREP_CT, PREP_CT_GATHER, PREP_HOST = 1, 2, 4, 8, 16, 32, 64
 FLAG_FINITE, FLAG_INFINITY, FLAG_REJECTED = 0, 1, 2
 
 
@@ -123,12 +123,12 @@ class Engine:
                                            (PREP_BASE if base else 0) | (PREP_BASE_LDS if base_lds else 0)
                                            | (PREP_CT if ct else 0) | (PREP_CT_GATHER if ct_gather else 0)))
 
-    def reserve(self, curve, max_n: int, *, var: bool = True, mirror: bool = False, ct: bool = False):
+    def reserve(self, curve, max_n: int, *, var: bool = True, mirror: bool = False, ct: bool = False, host: bool = False):
         """eccx_reserve: size the scratch slab and row buffer for batches of up to max_n units; ct: for the
         secret-scalar (ECCX_CT_SCAN) variable-base ladder."""
         self._check(self._lib.eccx_reserve(self._ctx, curve_id(curve), int(max_n),
                                            (PREP_VAR if var else 0) | (PREP_MIRROR if mirror else 0)
-                                           | (PREP_CT if ct else 0)))
+                                           | (PREP_CT if ct else 0) | (PREP_HOST if host else 0)))
 
     def device_bytes(self) -> int:
         return int(self._lib.eccx_device_bytes(self._ctx))

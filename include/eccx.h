@@ -149,6 +149,7 @@ enum {
   ECCX_PREP_BASE = 1u << 1,     /* fixed base and double-scalar: the comb tables of the curve */
   ECCX_PREP_BASE_LDS = 1u << 2, /* ECCX_TABLE_IN_LDS image (edwards25519) */
   ECCX_PREP_MIRROR = 1u << 3,   /* ECCX_MIRROR_REFERENCE / proj: slab of the mirror ladder */
+  ECCX_PREP_HOST = 1u << 6,     /* eccx_reserve: the device-side copies the HOST-buffer entry points keep of their arguments */
   ECCX_PREP_CT_GATHER = 1u << 5, /* ECCX_CT_SCAN | ECCX_CT_GATHER: eccx_prepare builds that form's table */
   ECCX_PREP_CT = 1u << 4        /* ECCX_CT_SCAN: eccx_prepare builds the signed-window table of the secret-scalar
                                    fixed-base kernel (99-460 KB); eccx_reserve sizes the slabs of the scanning

@@ -45,7 +45,9 @@ pub const ECCX_PREP_VAR: u32 = 1 << 0;
 pub const ECCX_PREP_BASE: u32 = 1 << 1;
 pub const ECCX_PREP_BASE_LDS: u32 = 1 << 2;
 pub const ECCX_PREP_MIRROR: u32 = 1 << 3;
+pub const ECCX_PREP_HOST: u32 = 1 << 6;
 pub const ECCX_PREP_CT_GATHER: u32 = 1 << 5;
+pub const ECCX_PREP_HOST: u32 = 1 << 6;
 pub const ECCX_PREP_CT_GATHER: u32 = 1 << 5;
 pub const ECCX_PREP_CT: u32 = 1 << 4; // ECCX_CT_SCAN: the secret-scalar fixed-base table / variable-base slabs
 

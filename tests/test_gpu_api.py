@@ -471,3 +471,42 @@ def test_garbage_bases_do_not_disturb_their_neighbours(engine, oracle, curve):
         else:
             for r in (got, chk):
                 assert r[0][i * 2 * fb:(i + 1) * 2 * fb] == want[0][i * 2 * fb:(i + 1) * 2 * fb] and r[1][i] == want[1][i]
+
+
+# ---- host-buffer entry points: nothing allocated or freed after warm-up ------------------------------
+def test_host_buffer_calls_allocate_nothing_after_warm_up(oracle):
+    """What the Rust crate calls (rust/eccoxide-gpu/src/weierstrass.rs: the host-buffer forms): device-side copies of
+    the arguments live in context-owned, grow-only buffers, so a steady stream of host calls neither allocates nor
+    frees device memory -- eccx_device_bytes stays put across 100 mixed calls -- and still returns the oracle's bytes."""
+    import eccoxide_amd as E
+
+    curve, n = "p256r1", 2048
+    ks = W.random_scalars(curve, n, seed=991).tobytes()
+    with E.Engine(0) as eng:
+        eng.prepare(curve, base=True, ct=True)
+        eng.reserve(curve, n, var=True, ct=True, host=True)
+        pts = eng.scalarmul_base(curve, ks)
+        # one call of each kind: whatever grows, grows now
+        eng.scalarmul_var(curve, ks, pts[0])
+        eng.scalarmul_var(curve, ks, pts[0], ct_scan=True)
+        eng.scalarmul_base(curve, ks, ct_scan=True)
+        eng.point_add(curve, pts[0], pts[0])
+        eng.double_scalarmul(curve, ks, ks, pts[0])
+        enc = eng.point_compress(curve, pts[0], pts[1])
+        eng.point_decompress(curve, enc)
+        before = eng.device_bytes()
+        want_v = oracle.var(curve, ks, pts[0], threads=16)
+        for i in range(100):
+            m = n - (i % 7) * 13
+            if i % 5 == 0:
+                got = eng.scalarmul_var(curve, ks[:m * 32], pts[0][:m * 64])
+                assert got[0] == want_v[0][:m * 64]
+            elif i % 5 == 1:
+                assert eng.scalarmul_base(curve, ks[:m * 32])[0] == pts[0][:m * 64]
+            elif i % 5 == 2:
+                assert eng.scalarmul_var(curve, ks[:m * 32], pts[0][:m * 64], ct_scan=True)[0] == want_v[0][:m * 64]
+            elif i % 5 == 3:
+                assert eng.point_decompress(curve, enc[:m * 33])[0] == pts[0][:m * 64]
+            else:
+                eng.point_add(curve, pts[0][:m * 64], pts[0][:m * 64])
+            assert eng.device_bytes() == before, i
