@@ -158,6 +158,8 @@ STEP_KERNELS = {
                     ["k_scalarmul_var_mirror_unsat<eccx::{U}>"]],
     ("dsm", "default"): [["k_scalarmul_coz_unsat<eccx::{U}, eccx::NoGlv, false, true, 5, false>", "k_scalarmul_coz_unsat<eccx::{U}, eccx::NoGlv, false, true>"],
                          ["k_scalarmul_var_unsat<eccx::{U}, true>"], ["k_batch_to_affine_unsat<eccx::{U}, 1,"]],
+    ("dsm", "xonly"): [["k_scalarmul_coz_unsat<eccx::{U}, eccx::NoGlv, false, true, 5, false>"], ["k_scalarmul_var_unsat<eccx::{U}, true>"],
+                       ["k_batch_to_affine_unsat<eccx::{U}, 4,"]],
     ("base", "default"): [["k_scalarmul_base_unsat<eccx::{U}>"], ["k_batch_to_affine_unsat<eccx::{U}, 1,"]],
     ("base", "ct"): [["k_scalarmul_base_ct<eccx::{U}, false>"], ["k_batch_to_affine_unsat<eccx::{U}, 1,"]],
     ("base", "ctg"): [["k_scalarmul_base_ct<eccx::{U}, true>"], ["k_batch_to_affine_unsat<eccx::{U}, 1,"]],
@@ -386,7 +388,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-buffer (PCIe-inclusive) measurement")
     ap.add_argument("--cpu-sample", type=int, default=1 << 17)
-    ap.add_argument("--variant", default="default", choices=["default", "mirror", "lds", "l2", "ct", "ctg", "glv"],
+    ap.add_argument("--variant", default="default", choices=["default", "mirror", "lds", "l2", "ct", "ctg", "glv", "xonly"],
                     help="default: fast kernels; mirror: reference-mirroring kernels; "
                          "lds: ed25519 fixed base with a signed 6-bit comb table resident in LDS; "
                          "l2: the reference's 4-bit comb read through L2; "
@@ -448,7 +450,9 @@ def main():
     else:
         eng.scalarmul_base_t(curve, ks[:256].contiguous())  # builds the comb table
         pts = None
-    out_cols = 32 if op == "x25519" else 2 * fb
+    out_cols = 32 if op == "x25519" else (fb if args.variant == "xonly" else 2 * fb)
+    if args.variant == "xonly":
+        alg_bytes -= fb  # u1 + u2 + Q in, x out: 160 bytes per p256r1 unit
     # two sets of output buffers: with N > 1 the gather of batch i runs while batch i+1 computes
     outs = [torch.empty((n, out_cols), dtype=torch.uint8, device=dev) for _ in range(2)]
     flagss = [torch.empty((n,), dtype=torch.uint8, device=dev) for _ in range(2)]
@@ -458,6 +462,9 @@ def main():
     mirror = args.variant == "mirror"
     ct = args.variant in ("ct", "ctg")
     ctg = args.variant == "ctg"
+    xonly = args.variant == "xonly"
+    if xonly and op != "dsm":
+        sys.exit("--variant xonly applies to the verify workloads")
     glv = args.variant == "glv"
     # one-time costs out of the timed region (and out of the _dev calls): tables + scratch
     if op in ("base", "dsm"):
@@ -470,7 +477,7 @@ def main():
             eng.scalarmul_var_t(curve, ks, pts, out, flags, stream=stream.cuda_stream, mirror=mirror, ct_scan=ct,
                                 assume_subgroup=glv)
         elif op == "dsm":
-            eng.double_scalarmul_t(curve, ks, ks2, pts, out, flags, stream=stream.cuda_stream)
+            eng.double_scalarmul_t(curve, ks, ks2, pts, out, flags, stream=stream.cuda_stream, x_only=xonly)
         elif op == "x25519":
             eng.x25519_t(ks, pts, out, flags, stream=stream.cuda_stream)
         else:
@@ -546,7 +553,10 @@ def main():
                 dec = lambda buf, fl, i: None if (fl[i] and not le) else (int.from_bytes(buf[i * pb:i * pb + fb], order),
                                                                          int.from_bytes(buf[i * pb + fb:(i + 1) * pb], order))
                 sums = [R.affine_add(c, dec(a_out, a_inf, i), dec(b_out, b_inf, i)) for i in range(len(a_inf))]
-                w_out = b"".join(bytes(pb) if t is None else t[0].to_bytes(fb, order) + t[1].to_bytes(fb, order) for t in sums)
+                if xonly:
+                    w_out = b"".join(bytes(fb) if t is None else t[0].to_bytes(fb, order) for t in sums)
+                else:
+                    w_out = b"".join(bytes(pb) if t is None else t[0].to_bytes(fb, order) + t[1].to_bytes(fb, order) for t in sums)
                 w_inf = bytes(1 if t is None else 0 for t in sums)
             elif op == "x25519":
                 w_out, w_inf = ora.x25519(s_k, s_pts, threads=8)

@@ -981,6 +981,8 @@ int eccx_double_scalarmul_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_
     ctx->set_err("eccx_double_scalarmul: no fused kernel for this curve");
     return ECCX_ERR_ARG;
   }
+  if ((opts & ECCX_OUT_X_ONLY) && !ops->to_affine_x)
+    return arg_err(ctx, "ECCX_OUT_X_ONLY: Weierstrass curves only (Ed25519 verification compares encoded points)");
   if (opts & ECCX_CT_SCAN) {  // the verify shape works on public data; no scanning form
     ctx->set_err("eccx_double_scalarmul: ECCX_CT_SCAN is not accepted (signature verification handles public data)");
     return ECCX_ERR_ARG;
@@ -1010,8 +1012,10 @@ int eccx_double_scalarmul_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_
   HIP_TRY(ctx, ops->var_fused(grid, s, n, static_cast<const uint8_t*>(d_u2), static_cast<const uint8_t*>(d_q), ctx->jac,
                               static_cast<uint8_t*>(d_flags), ctx->scratch, kopts | (ops->var_coz_fused ? K_ONLY_MARKED : 0u),
                               static_cast<const uint8_t*>(d_u1), ctx->comb_u[curve]));
-  HIP_TRY(ctx, ops->to_affine_var(norm_grid(ctx, n), s, n, ctx->jac, static_cast<uint8_t*>(d_out),
-                                  static_cast<uint8_t*>(d_flags)));
+  // ECCX_OUT_X_ONLY: the x-coordinate alone (what ECDSA verification compares with r): FB bytes per unit, one product less
+  HIP_TRY(ctx, ((opts & ECCX_OUT_X_ONLY) ? ops->to_affine_x : ops->to_affine_var)(norm_grid(ctx, n), s, n, ctx->jac,
+                                                                                  static_cast<uint8_t*>(d_out),
+                                                                                  static_cast<uint8_t*>(d_flags)));
   return ECCX_OK;
 }
 
@@ -1036,7 +1040,7 @@ int eccx_double_scalarmul(eccx_ctx* ctx, int curve, size_t n, const uint8_t* u1,
   HIP_TRY(ctx, hipMemcpyAsync(d_q, q, n * pb, hipMemcpyHostToDevice, ctx->stream));
   rc = eccx_double_scalarmul_dev(ctx, curve, n, d_u1, d_u2, d_q, d_o, d_f, opts, ctx->stream);
   if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
-  HIP_TRY(ctx, hipMemcpyAsync(out, d_o, n * pb, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(out, d_o, n * ((opts & ECCX_OUT_X_ONLY) ? pb / 2 : pb), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(flags, d_f, n, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return ECCX_OK;

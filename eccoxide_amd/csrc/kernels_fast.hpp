@@ -19,7 +19,7 @@ constexpr int FAST_TABLE_ROWS = 17;  // rows of the per-lane window table (entri
 // Thread t of a workgroup handles units tile + u*WG + t, u = 0..U-1, with one inversion.
 //   MODE 3: curve25519 x-only: u = X/Z with 0 for Z = 0, 32 little-endian bytes per unit,
 //           flag 1 = result is zero (curve25519.rs:529-532; x25519.rs:33-35)
-enum { NORM_HOMOGENEOUS = 0, NORM_JACOBIAN = 1, NORM_EDWARDS = 2, NORM_MONTGOMERY_U = 3 };
+enum { NORM_HOMOGENEOUS = 0, NORM_JACOBIAN = 1, NORM_EDWARDS = 2, NORM_MONTGOMERY_U = 3, NORM_JACOBIAN_X = 4 };
 template <class C, int MODE, int U>
 __global__ void __launch_bounds__(WG) k_batch_to_affine(size_t n, const uint32_t* __restrict__ pts,
                                                         uint8_t* __restrict__ out, uint8_t* __restrict__ flags) {

@@ -1400,6 +1400,8 @@ __global__ void __launch_bounds__(WG) k_ed_point_add_unsat(size_t n, const uint8
 //   NORM_JACOBIAN     x = X/Z^2, y = Y/Z^3, big-endian bytes; Z = 0 is infinity
 //   NORM_EDWARDS      x = X/Z, y = Y/Z, little-endian bytes, flag 1 = neutral element
 //   NORM_MONTGOMERY_U u = X/Z with 0 for Z = 0 (mod p), 32 little-endian bytes, flag 1 = zero result
+//   NORM_JACOBIAN_X   x = X/Z^2 only, FB big-endian bytes per unit (to_affine_x_ct, src/curve/projective.rs:690: what
+//                     ECDSA verification consumes, src/protocol/ecdsa.rs:383); Z = 0 is infinity
 // flags[i] on entry: 2 marks a rejected input (kept, zero output).
 template <class CU, int MODE, int UN>
 __global__ void __launch_bounds__(WG) k_batch_to_affine_unsat(size_t n, const uint32_t* __restrict__ rows,
@@ -1409,7 +1411,8 @@ __global__ void __launch_bounds__(WG) k_batch_to_affine_unsat(size_t n, const ui
   constexpr int FB = CS::FB;
   constexpr int W3 = urow3_words<CU>();
   using T = U<CU, 1, 3>;
-  static_assert(MODE == NORM_HOMOGENEOUS || MODE == NORM_JACOBIAN || MODE == NORM_EDWARDS || MODE == NORM_MONTGOMERY_U, "mode");
+  static_assert(MODE == NORM_HOMOGENEOUS || MODE == NORM_JACOBIAN || MODE == NORM_EDWARDS || MODE == NORM_MONTGOMERY_U ||
+                    MODE == NORM_JACOBIAN_X, "mode");
   const size_t tile_units = (size_t)WG * UN;
   for (size_t tile = (size_t)blockIdx.x * tile_units; tile < n; tile += (size_t)gridDim.x * tile_units) {
     T one;
@@ -1463,6 +1466,8 @@ __global__ void __launch_bounds__(WG) k_batch_to_affine_unsat(size_t n, const ui
         auto zi2 = u_sqr(zi);
         u_to_canonical<CU>(ax, u_mul(x, zi2));
         u_to_canonical<CU>(ay, u_mul(y, u_mul(zi2, zi)));
+      } else if constexpr (MODE == NORM_JACOBIAN_X) {
+        u_to_canonical<CU>(ax, u_mul(x, u_sqr(zi)));
       } else {
         u_to_canonical<CU>(ax, u_mul(x, zi));
         if constexpr (MODE == NORM_EDWARDS || MODE == NORM_HOMOGENEOUS) u_to_canonical<CU>(ay, u_mul(y, zi));
@@ -1484,6 +1489,12 @@ __global__ void __launch_bounds__(WG) k_batch_to_affine_unsat(size_t n, const ui
           fe_store_le<CS>(out + i * (size_t)(2 * FB), ax);
           fe_store_le<CS>(out + i * (size_t)(2 * FB) + FB, ay);
           flags[i] = rejected ? 2 : (neutral ? 1 : 0);
+        } else if constexpr (MODE == NORM_JACOBIAN_X) {
+          const bool ok = present & !rejected;
+#pragma unroll
+          for (int k = 0; k < L; ++k) ax.v[k] = ok ? ax.v[k] : 0u;
+          fe_store_be<CS>(out + i * (size_t)FB, ax);
+          flags[i] = rejected ? 2 : (present ? 0 : 1);
         } else if (fl != FLAG_REDO) {  // a unit marked from its BASE POINT is redone by the kernel launched behind
           const bool ok = present & !rejected;
 #pragma unroll

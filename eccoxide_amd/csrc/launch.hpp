@@ -114,6 +114,8 @@ struct CurveOps {
   hipError_t (*var_ct)(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint8_t* points, uint32_t* rows,
                        uint8_t* flags, uint32_t* scratch, uint32_t opts);
   int (*var_ct_grid)(int cus, size_t n);
+  // normalisation of Jacobian rows to the x-coordinate alone, FB bytes per unit (ECCX_OUT_X_ONLY; Weierstrass)
+  hipError_t (*to_affine_x)(int grid, hipStream_t s, size_t n, const uint32_t* rows, uint8_t* out, uint8_t* flags);
 };
 // units normalised per lane with one inversion: 16 where the prefix products fit the register
 // file (8-limb fields), 8 above

@@ -24,6 +24,7 @@ UNCOMPRESSED = 1 << 7
 CT_SCAN = 1 << 8
 ASSUME_SUBGROUP = 1 << 9
 CT_GATHER = 1 << 10
+OUT_X_ONLY = 1 << 11
 PREP_VAR, PREP_BASE, PREP_BASE_LDS, PREP_MIRROR, PREP_CT, PREP_CT_GATHER, PREP_HOST = 1, 2, 4, 8, 16, 32, 64
 FLAG_FINITE, FLAG_INFINITY, FLAG_REJECTED = 0, 1, 2
 
@@ -196,20 +197,23 @@ class Engine:
         return out.raw[: n * 2 * fb], flags.raw[:n]
 
     def double_scalarmul(self, curve, u1: bytes, u2: bytes, q: bytes, *, subtract: bool = False,
-                         validate: bool = False):
+                         validate: bool = False, x_only: bool = False):
         """out[i] = u1[i]*G + u2[i]*q[i] (minus with subtract=True): the signature-verification
-        shape (ECDSA u1*G + u2*Q, Ed25519 [s]B - [k]A).  Returns (affine bytes, flags)."""
+        shape (ECDSA u1*G + u2*Q, Ed25519 [s]B - [k]A).  Returns (affine bytes, flags); x_only=True: the
+        x-coordinates alone, FB bytes per unit (what ECDSA verification reads)."""
         cid = curve_id(curve)
         sb, fb = scalar_bytes(cid), field_bytes(cid)
         if len(u1) != len(u2) or len(u1) % sb or len(q) != (len(u1) // sb) * 2 * fb:
             raise ValueError("u1, u2 must be n x SB bytes and q n x 2FB bytes")
         n = len(u1) // sb
-        out = ctypes.create_string_buffer(max(1, n * 2 * fb))
+        width = fb if x_only else 2 * fb
+        out = ctypes.create_string_buffer(max(1, n * width))
         flags = ctypes.create_string_buffer(max(1, n))
         rc = self._lib.eccx_double_scalarmul(self._ctx, cid, n, u1, u2, q, out, flags,
-                                             (SUBTRACT if subtract else 0) | (VALIDATE_POINTS if validate else 0))
+                                             (SUBTRACT if subtract else 0) | (VALIDATE_POINTS if validate else 0)
+                                             | (OUT_X_ONLY if x_only else 0))
         self._check(rc)
-        return out.raw[: n * 2 * fb], flags.raw[:n]
+        return out.raw[: n * width], flags.raw[:n]
 
     def compressed_bytes(self, curve) -> int:
         """Bytes per compressed point: FB + 1 (SEC1), 48 (zcash G1), 32 (RFC 8032)."""
@@ -321,23 +325,25 @@ class Engine:
         return out, flags
 
     def double_scalarmul_t(self, curve, u1, u2, q, out=None, flags=None, *, subtract: bool = False,
-                           validate: bool = False, stream: Optional[int] = None):
+                           validate: bool = False, x_only: bool = False, stream: Optional[int] = None):
         """Device-tensor form of double_scalarmul (torch.uint8 CUDA tensors): out[i] = u1[i]*G +- u2[i]*q[i]."""
         import torch
 
         cid = curve_id(curve)
         fb, sb = field_bytes(cid), scalar_bytes(cid)
         n = self._units(u1, sb, "u1")
+        width = fb if x_only else 2 * fb
         if out is None:
-            out = torch.empty((n, 2 * fb), dtype=torch.uint8, device=u1.device)
+            out = torch.empty((n, width), dtype=torch.uint8, device=u1.device)
         if flags is None:
             flags = torch.empty((n,), dtype=torch.uint8, device=u1.device)
-        self._tensors(n, ("u1", u1, sb), ("u2", u2, sb), ("q", q, 2 * fb), ("out", out, 2 * fb), ("flags", flags, 1))
+        self._tensors(n, ("u1", u1, sb), ("u2", u2, sb), ("q", q, 2 * fb), ("out", out, width), ("flags", flags, 1))
         if stream is None:
             stream = torch.cuda.current_stream(u1.device).cuda_stream
         rc = self._lib.eccx_double_scalarmul_dev(self._ctx, cid, n, u1.data_ptr(), u2.data_ptr(), q.data_ptr(),
                                                  out.data_ptr(), flags.data_ptr(),
-                                                 (SUBTRACT if subtract else 0) | (VALIDATE_POINTS if validate else 0), stream)
+                                                 (SUBTRACT if subtract else 0) | (VALIDATE_POINTS if validate else 0)
+                                                 | (OUT_X_ONLY if x_only else 0), stream)
         self._check(rc)
         return out, flags
 

@@ -135,6 +135,9 @@ enum {
                                       digit steers the wavefront's register crossbar, whose time was MEASURED the same for
                                       every index pattern tried (profiles/r03_select_rates.jsonl) -- not an architectural
                                       guarantee, hence opt-in.  About 1.4x faster than the scan. */
+  ECCX_OUT_X_ONLY = 1u << 11,      /* eccx_double_scalarmul: write the x-coordinate alone, FB bytes per unit (`out` is then
+                                      n x FB): Point::to_affine_x_ct (src/curve/projective.rs:690), which is all ECDSA
+                                      verification reads (src/protocol/ecdsa.rs:383).  Weierstrass curves. */
   ECCX_ASSUME_SUBGROUP = 1u << 9   /* eccx_scalarmul_var, bls12_381_g1: the caller guarantees every base point
                                       is in the prime-order subgroup G1 (e.g. it was decoded under
                                       ECCX_CHECK_SUBGROUP, or is a multiple of the generator).  The
@@ -232,7 +235,7 @@ int eccx_point_add_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_a, cons
  * accumulated onto the same Jacobian point, one normalisation; edwards25519 likewise with the
  * complete extended-coordinate additions.
  *   u1, u2 : n x SB scalars      q : n x 2FB affine points      out, flags: as above
- * ECCX_VALIDATE_POINTS applies to q. */
+ * ECCX_VALIDATE_POINTS applies to q.  ECCX_OUT_X_ONLY: out is n x FB, the x-coordinates alone. */
 int eccx_double_scalarmul(eccx_ctx* ctx, int curve, size_t n, const uint8_t* u1, const uint8_t* u2,
                           const uint8_t* q, uint8_t* out, uint8_t* flags, uint32_t opts);
 /* Device-buffer form: inputs and outputs already in this device's memory, work enqueued on

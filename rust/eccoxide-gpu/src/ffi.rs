@@ -39,6 +39,7 @@ pub const ECCX_UNCOMPRESSED: u32 = 1 << 7;
 pub const ECCX_CT_SCAN: u32 = 1 << 8;
 pub const ECCX_ASSUME_SUBGROUP: u32 = 1 << 9;
 pub const ECCX_CT_GATHER: u32 = 1 << 10;
+pub const ECCX_OUT_X_ONLY: u32 = 1 << 11;
 
 // eccx_prepare / eccx_reserve
 pub const ECCX_PREP_VAR: u32 = 1 << 0;

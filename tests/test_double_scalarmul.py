@@ -169,3 +169,49 @@ def test_double_scalarmul_device_tensors(engine, oracle):
                                                t(q).reshape(n, -1), stream=stream.cuda_stream)
     stream.synchronize()
     assert out.cpu().numpy().tobytes() == want[0] and flags.cpu().numpy().tobytes() == want[1]
+
+
+@pytest.mark.parametrize("curve", ["p256r1", "p384r1", "p521r1", "bls12_381_g1"])
+def test_x_only_output(engine, oracle, curve):
+    """ECCX_OUT_X_ONLY: FB bytes per unit, the x of the full result (Point::to_affine_x_ct, src/curve/projective.rs:690,
+    consumed by verify at src/protocol/ecdsa.rs:383): the RFC 6979 signatures verify through it, infinity and rejected
+    inputs keep their flags, and every x equals the first half of the x||y output."""
+    c = R.CURVES[curve]
+    n = 300
+    u1 = bytearray(W.random_scalars(curve, n, seed=81).tobytes())
+    u2 = bytearray(W.random_scalars(curve, n, seed=82).tobytes())
+    q = bytearray(oracle.base(curve, W.random_scalars(curve, n, seed=83).tobytes(), threads=16)[0])
+    u1[0:c.sb] = bytes(c.sb)
+    u2[0:c.sb] = bytes(c.sb)                                 # unit 0: 0*G + 0*Q = infinity
+    q[5 * 2 * c.fb + c.fb - 1] ^= 1                          # unit 5: Q off the curve
+    u1, u2, q = bytes(u1), bytes(u2), bytes(q)
+    full, fl = engine.double_scalarmul(curve, u1, u2, q, validate=True)
+    xs, flx = engine.double_scalarmul(curve, u1, u2, q, validate=True, x_only=True)
+    assert len(xs) == n * c.fb and flx == fl and fl[0] == 1 and fl[5] == 2
+    for i in range(n):
+        assert xs[i * c.fb:(i + 1) * c.fb] == full[i * 2 * c.fb:i * 2 * c.fb + c.fb]
+    if curve in golden("rfc6979.json"):
+        v = golden("rfc6979.json")[curve]
+        qk = bytes.fromhex(v["ux"].rjust(2 * c.fb, "0")) + bytes.fromhex(v["uy"].rjust(2 * c.fb, "0"))
+        u1s, u2s, rs = b"", b"", []
+        for kat in v["sign_kats"]:
+            h = getattr(hashlib, kat["alg"])(kat["message"].encode()).digest()
+            e = int.from_bytes(h, "big")
+            if 8 * len(h) > c.n.bit_length():
+                e >>= 8 * len(h) - c.n.bit_length()
+            r, s = int(kat["r"], 16), int(kat["s"], 16)
+            w = pow(s, -1, c.n)
+            u1s += (e * w % c.n).to_bytes(c.sb, "big")
+            u2s += (r * w % c.n).to_bytes(c.sb, "big")
+            rs.append(r)
+        xs, flx = engine.double_scalarmul(curve, u1s, u2s, qk * len(rs), x_only=True)
+        assert all(f == 0 for f in flx)
+        assert [int.from_bytes(xs[i * c.fb:(i + 1) * c.fb], "big") % c.n for i in range(len(rs))] == rs
+
+
+def test_x_only_is_refused_for_edwards(engine):
+    import eccoxide_amd as E
+
+    with pytest.raises(E.EccxError) as ei:
+        engine.double_scalarmul("ed25519", bytes(32), bytes(32), bytes(64), x_only=True)
+    assert "X_ONLY" in str(ei.value)
