@@ -4,7 +4,7 @@
 use eccoxide::curve::bls12_381::g1::PointAffine;
 use eccoxide::curve::bls12_381::{Fp, Scalar};
 
-use crate::{ffi, GpuContext, GpuError, Secrecy};
+use crate::{ffi, GpuContext, GpuError, Secrecy, Unit};
 
 const FB: usize = 48;
 const SB: usize = 32;
@@ -16,18 +16,17 @@ fn push_point(buf: &mut Vec<u8>, p: &PointAffine) {
     buf.extend_from_slice(&y.to_bytes());
 }
 
-fn parse_points(out: &[u8], flags: &[u8]) -> Vec<Option<PointAffine>> {
+fn parse_points(out: &[u8], flags: &[u8]) -> Vec<Unit<PointAffine>> {
     flags
         .iter()
         .enumerate()
         .map(|(i, &f)| {
-            if f != ffi::ECCX_FLAG_FINITE {
-                return None;
-            }
-            let rec = &out[i * 2 * FB..(i + 1) * 2 * FB];
-            let x = Fp::from_bytes(rec[..FB].try_into().unwrap())?;
-            let y = Fp::from_bytes(rec[FB..].try_into().unwrap())?;
-            PointAffine::from_coordinate(&x, &y)
+            Unit::from_flag(f, || {
+                let rec = &out[i * 2 * FB..(i + 1) * 2 * FB];
+                let x = Fp::from_bytes(rec[..FB].try_into().unwrap())?;
+                let y = Fp::from_bytes(rec[FB..].try_into().unwrap())?;
+                PointAffine::from_coordinate(&x, &y)
+            })
         })
         .collect()
 }
@@ -46,7 +45,7 @@ pub enum Bases {
 /// `out[i] = (&Point::from_affine(&points[i]) * &scalars[i]).to_affine()` (g1.rs:38-41 ->
 /// curve_macros.rs:103-105, :321-327).
 pub fn mul_batch(ctx: &GpuContext, points: &[PointAffine], scalars: &[Scalar], bases: Bases, secrecy: Secrecy)
-                 -> Result<Vec<Option<PointAffine>>, GpuError> {
+                 -> Result<Vec<Unit<PointAffine>>, GpuError> {
     assert_eq!(points.len(), scalars.len());
     let n = points.len();
     let (mut k, mut xy) = (Vec::with_capacity(n * SB), Vec::with_capacity(n * 2 * FB));
@@ -54,7 +53,7 @@ pub fn mul_batch(ctx: &GpuContext, points: &[PointAffine], scalars: &[Scalar], b
         k.extend_from_slice(&s.to_bytes());
         push_point(&mut xy, p);
     }
-    let mut opts = secrecy.opts();
+    let mut opts = secrecy.opts_var();
     if bases == Bases::InSubgroup && secrecy == Secrecy::Public {
         opts |= ffi::ECCX_ASSUME_SUBGROUP;
     }
@@ -67,7 +66,7 @@ pub fn mul_batch(ctx: &GpuContext, points: &[PointAffine], scalars: &[Scalar], b
 }
 
 /// `out[i] = Point::mul_base(&scalars[i]).to_affine()` (curve_macros.rs:111-119).
-pub fn mul_base_batch(ctx: &GpuContext, scalars: &[Scalar], secrecy: Secrecy) -> Result<Vec<Option<PointAffine>>, GpuError> {
+pub fn mul_base_batch(ctx: &GpuContext, scalars: &[Scalar], secrecy: Secrecy) -> Result<Vec<Unit<PointAffine>>, GpuError> {
     let n = scalars.len();
     let mut k = Vec::with_capacity(n * SB);
     for s in scalars {
@@ -86,7 +85,7 @@ pub fn mul_base_batch(ctx: &GpuContext, scalars: &[Scalar], secrecy: Secrecy) ->
 /// point at infinity and every rejected encoding give `None`; `statuses` tells them apart
 /// (`ECCX_FLAG_INFINITY` / `ECCX_FLAG_REJECTED`).
 pub fn from_compressed_batch(ctx: &GpuContext, encodings: &[[u8; 48]], check_subgroup: bool)
-                             -> Result<(Vec<Option<PointAffine>>, Vec<u8>), GpuError> {
+                             -> Result<(Vec<Unit<PointAffine>>, Vec<u8>), GpuError> {
     let n = encodings.len();
     let enc: Vec<u8> = encodings.iter().flatten().copied().collect();
     let (mut out, mut flags) = (vec![0u8; n * 2 * FB], vec![0u8; n]);

@@ -2,7 +2,7 @@
 //! shape and the RFC 8032 point encoding over batches.
 use eccoxide::curve::curve25519::{FieldElement, Point, Scalar};
 
-use crate::{ffi, GpuContext, GpuError, Secrecy};
+use crate::{ffi, GpuContext, GpuError, Secrecy, Unit};
 
 const ID: core::ffi::c_int = ffi::ECCX_ED25519;
 
@@ -12,19 +12,20 @@ fn push_point(buf: &mut Vec<u8>, p: &Point) {
     buf.extend_from_slice(&y.to_bytes());
 }
 
-fn parse_points(out: &[u8], flags: &[u8]) -> Vec<Option<Point>> {
+/// Flag 1 marks the neutral element, which HAS affine coordinates (0, 1) on this curve: it comes back as
+/// `Unit::Point(identity)`, never as `Unit::Infinity`; only a rejected input gives `Unit::Rejected`.
+fn parse_points(out: &[u8], flags: &[u8]) -> Vec<Unit<Point>> {
     flags
         .iter()
         .enumerate()
         .map(|(i, &f)| {
-            if f == ffi::ECCX_FLAG_REJECTED {
-                return None;
-            }
-            // flag 1 marks the neutral element, which has affine coordinates (0, 1) on this curve
-            let rec = &out[i * 64..(i + 1) * 64];
-            let x = FieldElement::from_bytes(rec[..32].try_into().unwrap())?;
-            let y = FieldElement::from_bytes(rec[32..].try_into().unwrap())?;
-            Point::from_coordinate(&x, &y)
+            let as_finite = if f == ffi::ECCX_FLAG_INFINITY { ffi::ECCX_FLAG_FINITE } else { f };
+            Unit::from_flag(as_finite, || {
+                let rec = &out[i * 64..(i + 1) * 64];
+                let x = FieldElement::from_bytes(rec[..32].try_into().unwrap())?;
+                let y = FieldElement::from_bytes(rec[32..].try_into().unwrap())?;
+                Point::from_coordinate(&x, &y)
+            })
         })
         .collect()
 }
@@ -32,7 +33,7 @@ fn parse_points(out: &[u8], flags: &[u8]) -> Vec<Option<Point>> {
 /// `out[i] = points[i].scale(&scalars[i])` (curve25519.rs:746-762).  The library takes the scalar as
 /// the big-endian string the reference's loop indexes (`Scalar::to_bytes_be`).
 pub fn scale_batch(ctx: &GpuContext, points: &[Point], scalars: &[Scalar], secrecy: Secrecy)
-                   -> Result<Vec<Option<Point>>, GpuError> {
+                   -> Result<Vec<Unit<Point>>, GpuError> {
     assert_eq!(points.len(), scalars.len());
     let n = points.len();
     let (mut k, mut xy) = (Vec::with_capacity(n * 32), Vec::with_capacity(n * 64));
@@ -43,13 +44,13 @@ pub fn scale_batch(ctx: &GpuContext, points: &[Point], scalars: &[Scalar], secre
     let (mut out, mut flags) = (vec![0u8; n * 64], vec![0u8; n]);
     ctx.check(unsafe {
         ffi::eccx_scalarmul_var(ctx.raw(), ID, n, k.as_ptr(), xy.as_ptr(), out.as_mut_ptr(), flags.as_mut_ptr(),
-                                core::ptr::null_mut(), secrecy.opts())
+                                core::ptr::null_mut(), secrecy.opts_var())
     })?;
     Ok(parse_points(&out, &flags))
 }
 
 /// `out[i] = Point::mul_base(&scalars[i])` (curve25519.rs:840-851): Ed25519 key generation / signing.
-pub fn mul_base_batch(ctx: &GpuContext, scalars: &[Scalar], secrecy: Secrecy) -> Result<Vec<Option<Point>>, GpuError> {
+pub fn mul_base_batch(ctx: &GpuContext, scalars: &[Scalar], secrecy: Secrecy) -> Result<Vec<Unit<Point>>, GpuError> {
     let n = scalars.len();
     let mut k = Vec::with_capacity(n * 32);
     for s in scalars {
@@ -65,7 +66,7 @@ pub fn mul_base_batch(ctx: &GpuContext, scalars: &[Scalar], secrecy: Secrecy) ->
 
 /// `[s]B - [k]A` for a batch: what `Point::double_scalar_mul_base_vartime` computes in Ed25519
 /// verification (curve25519.rs:1157-1183, src/protocol/ed25519.rs:145).
-pub fn verify_points(ctx: &GpuContext, s: &[Scalar], k: &[Scalar], a: &[Point]) -> Result<Vec<Option<Point>>, GpuError> {
+pub fn verify_points(ctx: &GpuContext, s: &[Scalar], k: &[Scalar], a: &[Point]) -> Result<Vec<Unit<Point>>, GpuError> {
     assert!(s.len() == k.len() && s.len() == a.len());
     let n = a.len();
     let (mut u1, mut u2, mut xy) = (Vec::with_capacity(n * 32), Vec::with_capacity(n * 32), Vec::with_capacity(n * 64));
@@ -83,7 +84,7 @@ pub fn verify_points(ctx: &GpuContext, s: &[Scalar], k: &[Scalar], a: &[Point]) 
 }
 
 /// RFC 8032 `decode_point` (src/protocol/ed25519.rs:38-59) over a batch of 32-byte encodings.
-pub fn decode_points(ctx: &GpuContext, encodings: &[[u8; 32]]) -> Result<Vec<Option<Point>>, GpuError> {
+pub fn decode_points(ctx: &GpuContext, encodings: &[[u8; 32]]) -> Result<Vec<Unit<Point>>, GpuError> {
     let n = encodings.len();
     let enc: Vec<u8> = encodings.iter().flatten().copied().collect();
     let (mut out, mut flags) = (vec![0u8; n * 64], vec![0u8; n]);

@@ -11,13 +11,19 @@
 //!
 //! ```ignore
 //! let gpu = eccoxide_gpu::GpuContext::new(0)?;
-//! let out = eccoxide_gpu::p256r1::mul_batch(&gpu, &points, &scalars, Default::default())?;
-//! assert_eq!(out[0], (&Point::from_affine(&points[0]) * &scalars[0]).to_affine());
+//! let out = eccoxide_gpu::p256r1::mul_batch(&gpu, &points, &scalars, Secrecy::Secret)?;
+//! assert_eq!(out[0].clone().point(), (&Point::from_affine(&points[0]) * &scalars[0]).to_affine());
 //! ```
 //!
-//! Side channels: the default kernels are NOT constant-time (table lookups indexed by scalar digits);
-//! pass [`Secrecy::Secret`] where the scalars are secret (key generation, signing, ECDH) -- it selects
-//! `ECCX_CT_SCAN`, the reference's full-table scan on its own formulas.  See `include/eccx.h`.
+//! Side channels: every scalar-multiplication function takes a [`Secrecy`] and there is no default --
+//! the reference's `*` and `mul_base` are constant-time, so a drop-in caller has to say which it needs.
+//! [`Secrecy::Secret`] (key generation, signing, ECDH) selects `ECCX_CT_SCAN`: no memory address and no
+//! branch depends on a scalar digit; [`Secrecy::Public`] (signature verification, public-key checks)
+//! the faster kernels that index their tables by scalar digits.  See `include/eccx.h`.
+//!
+//! STATUS: this crate has never been compiled -- the build image has no Rust toolchain.  `ffi.rs` is
+//! checked against `include/eccx.h` mechanically (`tools/check_rust_ffi.py`), the wrappers only by eye
+//! and by that script's lints (macro fragments, the eccoxide items they name).
 
 pub mod ffi;
 
@@ -44,14 +50,19 @@ impl fmt::Display for GpuError {
 }
 impl std::error::Error for GpuError {}
 
-/// Whether the scalars of a call are secret.
-#[derive(Debug, Clone, Copy, PartialEq, Eq, Default)]
+/// Whether the scalars of a call are secret.  Deliberately without a `Default`.
+#[derive(Debug, Clone, Copy, PartialEq, Eq)]
 pub enum Secrecy {
-    /// Public scalars (signature verification, public-key validation): the fast kernels.
-    #[default]
+    /// Public scalars (signature verification, public-key validation): the fast kernels, whose table
+    /// lookups are indexed by scalar digits.
     Public,
-    /// Secret scalars: `ECCX_CT_SCAN` (no scalar-dependent address or branch).
+    /// Secret scalars: `ECCX_CT_SCAN` -- every table entry read at every lookup, selects instead of
+    /// branches (what the reference's own `select_from_table` does).
     Secret,
+    /// Secret scalars, fixed base only: `ECCX_CT_SCAN | ECCX_CT_GATHER` -- the lookup is a cross-lane
+    /// register gather inside the wavefront (no memory address depends on a digit; its timing was measured
+    /// uniform, which is not an architectural guarantee).  About 1.4x faster than `Secret`.
+    SecretLaneGather,
 }
 
 impl Secrecy {
@@ -59,6 +70,46 @@ impl Secrecy {
         match self {
             Secrecy::Public => 0,
             Secrecy::Secret => ffi::ECCX_CT_SCAN,
+            Secrecy::SecretLaneGather => ffi::ECCX_CT_SCAN | ffi::ECCX_CT_GATHER,
+        }
+    }
+    /// For the entry points that have no gather form (variable base): plain `ECCX_CT_SCAN`.
+    pub(crate) fn opts_var(self) -> u32 {
+        match self {
+            Secrecy::Public => 0,
+            _ => ffi::ECCX_CT_SCAN,
+        }
+    }
+}
+
+/// One unit of a batch result: the library's three flag values kept apart (`ECCX_FLAG_*`).
+#[derive(Debug, Clone, PartialEq, Eq)]
+pub enum Unit<P> {
+    /// A finite point.
+    Point(P),
+    /// The point at infinity / neutral element (the reference's `to_affine() == None`).
+    Infinity,
+    /// The input of this unit was rejected (not canonical, not on the curve, not in the subgroup), or the
+    /// library's bytes did not parse back through the crate's checked constructors.
+    Rejected,
+}
+
+impl<P> Unit<P> {
+    /// `Some` for a finite point, `None` for infinity AND for a rejected unit (the reference's `Option`).
+    pub fn point(self) -> Option<P> {
+        match self {
+            Unit::Point(p) => Some(p),
+            _ => None,
+        }
+    }
+    pub fn is_rejected(&self) -> bool {
+        matches!(self, Unit::Rejected)
+    }
+    pub(crate) fn from_flag(flag: u8, parse: impl FnOnce() -> Option<P>) -> Self {
+        match flag {
+            ffi::ECCX_FLAG_FINITE => parse().map_or(Unit::Rejected, Unit::Point),
+            ffi::ECCX_FLAG_INFINITY => Unit::Infinity,
+            _ => Unit::Rejected,
         }
     }
 }
@@ -101,7 +152,10 @@ impl GpuContext {
 
     /// Size the scratch buffers for batches of up to `max_n` units of `curve` (`eccx_reserve`).
     pub fn reserve(&self, curve: Curve, max_n: usize) -> Result<(), GpuError> {
-        self.check(unsafe { ffi::eccx_reserve(self.raw, curve.id(), max_n, ffi::ECCX_PREP_VAR | ffi::ECCX_PREP_MIRROR) })
+        // the batch functions of this crate call the host-buffer entry points: their device-side copies too
+        self.check(unsafe {
+            ffi::eccx_reserve(self.raw, curve.id(), max_n, ffi::ECCX_PREP_VAR | ffi::ECCX_PREP_CT | ffi::ECCX_PREP_HOST)
+        })
     }
 
     /// Device memory the context owns.

@@ -1,15 +1,16 @@
 //! Batch forms of the sec2 curves' `Point` / `PointAffine` operations
 //! (`fiat_define_weierstrass_points!`, `src/curve/fiat/curve_macros.rs:157-411`).
 
-/// Generates one module per curve.  `$path` is the curve's module in eccoxide, `$id` its
-/// `eccx_curve`, `$fb` / `$sb` its field and scalar sizes in bytes.
+/// Generates one module per curve.  `$seg::...` is the curve's module in eccoxide (matched as identifiers:
+/// a `path` fragment cannot be extended with `::{...}` in a `use`), `$id` its `eccx_curve`, `$fb` / `$sb`
+/// its field and scalar sizes in bytes.
 macro_rules! gpu_weierstrass_curve {
-    ($modname:ident, $path:path, $id:expr, $fb:expr, $sb:expr) => {
+    ($modname:ident, $($seg:ident)::+, $id:expr, $fb:expr, $sb:expr) => {
         pub mod $modname {
-            use $path::{FieldElement, PointAffine, Scalar};
+            use $($seg)::+::{FieldElement, PointAffine, Scalar};
             use eccoxide::curve::Sign;
 
-            use crate::{ffi, GpuContext, GpuError, Secrecy};
+            use crate::{ffi, GpuContext, GpuError, Secrecy, Unit};
 
             const FB: usize = $fb;
             const SB: usize = $sb;
@@ -20,18 +21,17 @@ macro_rules! gpu_weierstrass_curve {
                 buf.extend_from_slice(&y.to_bytes());
             }
 
-            fn parse_points(out: &[u8], flags: &[u8]) -> Vec<Option<PointAffine>> {
+            fn parse_points(out: &[u8], flags: &[u8]) -> Vec<Unit<PointAffine>> {
                 flags
                     .iter()
                     .enumerate()
                     .map(|(i, &f)| {
-                        if f != ffi::ECCX_FLAG_FINITE {
-                            return None; // infinity (to_affine() == None) or a rejected input
-                        }
-                        let rec = &out[i * 2 * FB..(i + 1) * 2 * FB];
-                        let x = FieldElement::from_bytes(rec[..FB].try_into().unwrap())?;
-                        let y = FieldElement::from_bytes(rec[FB..].try_into().unwrap())?;
-                        PointAffine::from_coordinate(&x, &y)
+                        Unit::from_flag(f, || {
+                            let rec = &out[i * 2 * FB..(i + 1) * 2 * FB];
+                            let x = FieldElement::from_bytes(rec[..FB].try_into().unwrap())?;
+                            let y = FieldElement::from_bytes(rec[FB..].try_into().unwrap())?;
+                            PointAffine::from_coordinate(&x, &y)
+                        })
                     })
                     .collect()
             }
@@ -39,7 +39,7 @@ macro_rules! gpu_weierstrass_curve {
             /// `out[i] = (&Point::from_affine(&points[i]) * &scalars[i]).to_affine()`
             /// (`impl Mul<&Scalar> for &Point`, curve_macros.rs:321-327).
             pub fn mul_batch(ctx: &GpuContext, points: &[PointAffine], scalars: &[Scalar], secrecy: Secrecy)
-                             -> Result<Vec<Option<PointAffine>>, GpuError> {
+                             -> Result<Vec<Unit<PointAffine>>, GpuError> {
                 assert_eq!(points.len(), scalars.len());
                 let n = points.len();
                 let mut k = Vec::with_capacity(n * SB);
@@ -51,14 +51,14 @@ macro_rules! gpu_weierstrass_curve {
                 let (mut out, mut flags) = (vec![0u8; n * 2 * FB], vec![0u8; n]);
                 ctx.check(unsafe {
                     ffi::eccx_scalarmul_var(ctx.raw(), $id, n, k.as_ptr(), xy.as_ptr(), out.as_mut_ptr(),
-                                            flags.as_mut_ptr(), core::ptr::null_mut(), secrecy.opts())
+                                            flags.as_mut_ptr(), core::ptr::null_mut(), secrecy.opts_var())
                 })?;
                 Ok(parse_points(&out, &flags))
             }
 
             /// `out[i] = Point::mul_base(&scalars[i]).to_affine()` (curve_macros.rs:55-63).
             pub fn mul_base_batch(ctx: &GpuContext, scalars: &[Scalar], secrecy: Secrecy)
-                                  -> Result<Vec<Option<PointAffine>>, GpuError> {
+                                  -> Result<Vec<Unit<PointAffine>>, GpuError> {
                 let n = scalars.len();
                 let mut k = Vec::with_capacity(n * SB);
                 for s in scalars {
@@ -75,7 +75,7 @@ macro_rules! gpu_weierstrass_curve {
             /// ECDSA verification's point `u1*G + u2*Q` for a batch (src/protocol/ecdsa.rs:215), one
             /// fused kernel; public data only.
             pub fn verify_points(ctx: &GpuContext, u1: &[Scalar], u2: &[Scalar], q: &[PointAffine])
-                                 -> Result<Vec<Option<PointAffine>>, GpuError> {
+                                 -> Result<Vec<Unit<PointAffine>>, GpuError> {
                 assert!(u1.len() == u2.len() && u1.len() == q.len());
                 let n = q.len();
                 let (mut k1, mut k2) = (Vec::with_capacity(n * SB), Vec::with_capacity(n * SB));
@@ -96,7 +96,7 @@ macro_rules! gpu_weierstrass_curve {
             /// `out[i] = a[i] + b[i]`, or `a[i] - b[i]` with `subtract` (impl Add / Sub for Point,
             /// curve_macros.rs:349-411); `None` operands are the point at infinity.
             pub fn add_batch(ctx: &GpuContext, a: &[Option<PointAffine>], b: &[Option<PointAffine>], subtract: bool)
-                             -> Result<Vec<Option<PointAffine>>, GpuError> {
+                             -> Result<Vec<Unit<PointAffine>>, GpuError> {
                 assert_eq!(a.len(), b.len());
                 let n = a.len();
                 let marshal = |ps: &[Option<PointAffine>]| {
@@ -127,7 +127,7 @@ macro_rules! gpu_weierstrass_curve {
             /// `PointAffine::decompress(&xs[i], signs[i])` (curve_macros.rs:221-223): the SEC1 prefix is
             /// the `Sign` (`Negative` = y odd, field_macros.rs:557-565).
             pub fn decompress_batch(ctx: &GpuContext, xs: &[FieldElement], signs: &[Sign])
-                                    -> Result<Vec<Option<PointAffine>>, GpuError> {
+                                    -> Result<Vec<Unit<PointAffine>>, GpuError> {
                 assert_eq!(xs.len(), signs.len());
                 let n = xs.len();
                 let mut enc = Vec::with_capacity(n * (FB + 1));

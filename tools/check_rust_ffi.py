@@ -8,10 +8,16 @@ script is what keeps its `extern "C"` block honest.  It parses both files and fa
     is not the Rust spelling of the C type,
   * an enum constant of the header that is missing from ffi.rs or has another value,
   * an `ffi::name` used by the wrapper modules that ffi.rs does not declare,
+  * a macro fragment of kind `path` or `ty` that the macro body then extends with `::` (rustc rejects
+    `use $p::{..}` for `$p:path`: the construct that sat in weierstrass.rs through round 2),
+  * an `eccoxide::...` path segment, an imported eccoxide item, or a method called on the crate's values that the
+    reference does not define (against rust/eccoxide-gpu/reference_items.json, the public item NAMES extracted from
+    the reference as text by tools/extract_rust_items.py),
   * unbalanced brackets in any source file of the crate (a cheap guard against truncated edits).
 
     python tools/check_rust_ffi.py          # exit code 0 = in sync
 """
+import json
 import os
 import re
 import sys
@@ -109,6 +115,67 @@ def balanced(path):
     return not stack
 
 
+# methods of std / core types the wrappers call; anything else called with `.name(` must be an eccoxide item
+STD_METHODS = {
+    "iter", "enumerate", "map", "collect", "zip", "copied", "flatten", "unwrap", "try_into", "extend_from_slice", "len", "push",
+    "as_ptr", "as_mut_ptr", "chunks_exact", "to_string_lossy", "into_owned", "is_empty", "clone", "extend", "take", "map_or",
+    "raw", "check", "opts", "opts_var", "id", "sizes", "point", "is_rejected", "device", "to_vec", "into_iter", "get", "any", "all",
+    "filter", "unwrap_or", "ok_or", "cloned", "as_slice", "first", "last", "rev", "sum", "fmt", "to_string", "join", "display",
+    "exists", "is_some", "is_none", "as_ref", "as_mut", "as_deref",
+}
+
+
+def lint_wrappers(files):
+    """Lints that need no compiler: fragment misuse in macro_rules, and names against the reference's item list."""
+    errors = []
+    items_path = os.path.join(CRATE, "reference_items.json")
+    ref = json.load(open(items_path))["files"] if os.path.exists(items_path) else None
+    names = set()
+    mods = {"eccoxide", "curve", "protocol"}
+    if ref:
+        for f, kinds in ref.items():
+            for kind, vals in kinds.items():
+                names |= set(vals)
+                if kind == "mod":
+                    mods |= set(vals)
+    for path in files:
+        rel = os.path.relpath(path, ROOT)
+        txt = strip_rust_comments(open(path).read())
+        # (1) `$x:path` / `$x:ty` fragments followed by `::` in the expansion
+        for mac in re.finditer(r"macro_rules!\s*\w+\s*\{(.*?)\n\}", txt, flags=re.S):
+            body = mac.group(1)
+            for frag, kind in re.findall(r"\$(\w+):(path|ty)\b", body):
+                if re.search(r"\$" + frag + r"\s*::", body):
+                    errors.append(f"{rel}: macro fragment ${frag}:{kind} is extended with `::` (not accepted by rustc; match `$($seg:ident)::+` instead)")
+        if ref is None:
+            continue
+        # (2) eccoxide paths: every module segment and every imported item must exist in the reference
+        for m in re.finditer(r"\beccoxide((?:::\w+)+)(?:::\{([^}]*)\})?", txt):
+            segs = [x for x in m.group(1).split("::") if x]
+            leaf_items = [x.strip() for x in (m.group(2) or "").split(",") if x.strip()]
+            if not leaf_items:
+                leaf_items, segs = [segs[-1]], segs[:-1]
+            for sgm in segs:
+                if sgm not in mods and sgm not in names:
+                    errors.append(f"{rel}: eccoxide::...::{sgm}: no such module in the reference's item list")
+            for it in leaf_items:
+                if it not in names and it not in mods:
+                    errors.append(f"{rel}: eccoxide item {it} is not in the reference's item list")
+        # (3) methods and associated functions
+        for meth in sorted(set(re.findall(r"\.([a-z_][a-z0-9_]*)\(", txt))):
+            if meth not in STD_METHODS and meth not in names:
+                errors.append(f"{rel}: method .{meth}() is neither a known std method nor an item of the reference")
+        for typ, fn in sorted(set(re.findall(r"\b([A-Z]\w+)::([a-z_][a-z0-9_]*)\(", txt))):
+            if typ in ("Vec", "Self", "GpuError", "GpuContext", "Unit", "CStr", "String", "Some", "Ok", "Err", "Curve", "Secrecy", "Bases"):
+                continue
+            if fn not in names:
+                errors.append(f"{rel}: {typ}::{fn}() is not an item of the reference")
+        for typ, var in sorted(set(re.findall(r"\b(Sign)::([A-Z]\w+)", txt))):
+            if f"{typ}::{var}" not in names:
+                errors.append(f"{rel}: enum variant {typ}::{var} is not in the reference's item list")
+    return errors
+
+
 def check():
     errors = []
     c_funcs, c_consts = parse_header()
@@ -153,6 +220,7 @@ def check():
         for used in sorted(set(re.findall(r"ffi::((?:eccx|ECCX)_\w+)", strip_rust_comments(open(path).read())))):
             if used not in declared:
                 errors.append(f"{os.path.relpath(path, ROOT)}: uses ffi::{used}, which ffi.rs does not declare")
+    errors += lint_wrappers([f for f in files if not f.endswith("ffi.rs") and not f.endswith("build.rs")])
     return errors, len(c_funcs), len(c_consts)
 
 
