@@ -283,18 +283,29 @@ constexpr int coz_full_windows() {
 #endif
 
 // Waves per SIMD the kernel is compiled for: the mixed additions keep two coordinates of an entry live where
-// the generic ladder keeps five, so the 14-limb fields fit three waves (measured against two: P-384 19.49 ->
-// 18.67 ms, BLS12-381 34.55 -> 34.07 ms; the generic 14-limb ladder was 8 % SLOWER at three, and the GLV form,
-// whose rows carry a third column, loses 0.7 %: it stays at two).  9 limbs: three equal to four, five +5.5 %;
-// 18 limbs: three +16 %.
+// the generic ladder keeps five, so the 14-limb fields fit three waves at the price of spilling (448 B of scratch
+// per lane against 76-80 at two waves).  Same-box A/B with the counters beside the time (round 3,
+// profiles/r03_occ14_ab.json):
+//   P-384      3 waves 18.94 ms, 4.55 GB written   2 waves 19.71 ms (+4.1 %), 3.42 GB     -> three
+//   BLS12-381  3 waves 34.31 ms, 12.82 GB written  2 waves 34.57 ms (+0.7 %), 6.53 GB     -> two: the 6.3 GB are the
+//              spill frame rewritten ~13 times per unit (the resident frames, 88 MB, do not fit the 32 MB of L2), and the
+//              higher clock the two-wave build holds (2.30 against 2.25 GHz) returns what its 3 % more cycles per
+//              instruction cost.  The GLV form, whose rows carry a third column, was 0.7 % slower at three already.
+// 9 limbs: three equal to four, five +5.5 %; 18 limbs: three +16 %.
 #ifndef ECCX_COZ_OCC_U14
 #define ECCX_COZ_OCC_U14 3
+#endif
+#ifndef ECCX_COZ_OCC_BLS
+#define ECCX_COZ_OCC_BLS 2
 #endif
 #ifndef ECCX_COZ_OCC_U9
 #define ECCX_COZ_OCC_U9 4
 #endif
 template <class CU, bool GLV>
-constexpr int coz_occupancy() { return CU::N <= 9 ? ECCX_COZ_OCC_U9 : (CU::N <= 14 ? (GLV ? ECCX_OCC_U14 : ECCX_COZ_OCC_U14) : ECCX_OCC_U18); }
+constexpr int coz_occupancy() {
+  return CU::N <= 9 ? ECCX_COZ_OCC_U9
+                    : (CU::N <= 14 ? (GLV ? ECCX_OCC_U14 : (CU::KIND == UK_MONT ? ECCX_COZ_OCC_BLS : ECCX_COZ_OCC_U14)) : ECCX_OCC_U18);
+}
 
 // scratch: [workgroup][row 0..16][thread][urowc_words]; row 0: split scalar (words 0..15, GLV) and
 // zeta (words 16..16+N); rows 1..16: the table.

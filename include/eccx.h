@@ -48,11 +48,23 @@
  * tables at addresses chosen by scalar digits and take wave-uniform branches on data-dependent
  * ballots (accumulator at infinity, equal points).  They return the same bytes, and are meant for
  * PUBLIC scalars (signature verification, public-key checks) or callers who accept that.  For
- * secret scalars (key generation, signing, ECDH) pass ECCX_CT_SCAN: the reference-mirroring kernels
- * with the full-table scan -- complete formulas, no digit-dependent address, no digit-dependent
- * branch (the cost is in DESIGN.md section 3).  No timing measurements back either claim: GPU
- * schedulers and caches are not modelled.  eccx_x25519 is uniform by construction (conditional
- * swaps are selects, no table).
+ * secret scalars (key generation, signing, ECDH) pass ECCX_CT_SCAN.  What that option guarantees is a
+ * STRUCTURE, checked on the compiled code (tools/isa_histogram.py --branches, profiles/r03_isa_ct_*.txt):
+ *   - no memory address depends on a scalar digit: every lookup reads every entry of its table (fixed base:
+ *     the window's slice, staged in LDS by the workgroup; variable base: all rows of the lane's own table)
+ *     and keeps one with v_cndmask; the scalar bytes are read at addresses that depend on the window number;
+ *   - no branch depends on scalar-derived data: signs, digit 0, accumulator at infinity and accumulator ==
+ *     +-entry are resolved by selects (written as inline assembly: the compiler otherwise turns ?: into EXEC-
+ *     masked regions it can skip); the conditional branches left are loop counters and batch bounds;
+ *   - the batched normalisation substitutes Z = 0 and zeroes outputs by selects as well.
+ * What still depends on data under ECCX_CT_SCAN: the BASE POINT -- rejected inputs (ECCX_VALIDATE_POINTS), a base
+ * of order <= 8 (bls12_381_g1 cofactor points; never on a prime-order curve) or bytes that are no curve point
+ * mark the unit, from the point alone, and it is redone by the reference-mirroring scan kernel; which units those
+ * are is visible in timing.  edwards25519 VARIABLE base under ECCX_CT_SCAN is the reference's bit-serial
+ * double-and-add with masked additions (no table).  ECCX_CT_GATHER (opt-in, fixed base) replaces the scan by a
+ * cross-lane register gather; see the option.  No timing measurement backs a constant-time claim beyond the
+ * microbenchmarks named there: GPU schedulers, caches and DVFS are not modelled.  eccx_x25519 is uniform by
+ * construction (conditional swaps are selects, no table).
  *
  * MEMORY AND BLOCKING.  A context is bound to one GPU and owns
  *   - the window-table slab of the variable-base ladders: resident lanes x 17 rows (P-256:
@@ -60,7 +72,10 @@
  *   - a buffer of un-normalised result rows, 112-224 bytes per unit of the largest batch seen,
  *   - the fixed-base tables of each curve used: the 16-bit-window table (134 MB for p256r1,
  *     ed25519 and bls12_381_g1, 201 MB p384r1, 415 MB p521r1), the reference-layout comb
- *     (64-265 KB), and for ECCX_TABLE_IN_LDS a 155 KB image.
+ *     (64-265 KB), for ECCX_TABLE_IN_LDS a 155 KB image, for ECCX_CT_SCAN / ECCX_CT_GATHER a signed-window
+ *     table each (0.1-0.5 MB),
+ *   - the device-side copies the HOST-buffer entry points keep of their arguments (sized by the largest batch
+ *     seen, or by eccx_reserve with ECCX_PREP_HOST): those calls allocate and free nothing once warm.
  * eccx_device_bytes() reports the total.  The buffers grow on demand: a call with a batch larger
  * than any before frees and reallocates them after a device-wide synchronisation, and the first
  * fixed-base / double-scalar call per curve builds the tables (64-271 ms) after waiting for the
@@ -122,13 +137,15 @@ enum {
   ECCX_SUBTRACT = 1u << 5,         /* eccx_point_add: compute a - b */
   ECCX_CHECK_SUBGROUP = 1u << 6,   /* eccx_point_decompress, bls12_381_g1: reject points outside G1 */
   ECCX_UNCOMPRESSED = 1u << 7,     /* eccx_point_[de]compress, bls12_381_g1: the 96-byte zcash flavour */
-  ECCX_CT_SCAN = 1u << 8,          /* eccx_scalarmul_var / _base: secret scalars.  Runs the reference-mirroring
-                                      kernels (complete RCB / unified Edwards formulas, fixed 4-bit
-                                      windows; edwards25519 variable base: the reference's bit-serial
-                                      double-and-add) with select_from_table's scan of all 16 entries
-                                      (src/curve/projective.rs:427-434, curve25519.rs:862-869): no memory
-                                      address and no branch depends on a scalar digit.  Same bytes out.
-                                      Not accepted by eccx_double_scalarmul (public data). */
+  ECCX_CT_SCAN = 1u << 8,          /* eccx_scalarmul_var / _base: secret scalars (see SIDE CHANNELS above).  Fixed base: signed
+                                      6-bit windows (edwards25519: 5), every entry of the window read by every lane, XYZZ mixed
+                                      additions with select-only special cases / complete Edwards additions.  Variable base,
+                                      Weierstrass: the affine-table ladder with signed 4-bit windows, all 8 rows of the lane's
+                                      table read at every lookup; edwards25519: the reference's bit-serial double-and-add.  With
+                                      ECCX_MIRROR_REFERENCE (or proj): the reference-mirroring kernels with select_from_table's
+                                      scan (src/curve/projective.rs:427-434, curve25519.rs:862-869).  Same bytes out.
+                                      Not accepted by eccx_double_scalarmul (public data), nor with ECCX_ASSUME_SUBGROUP or
+                                      ECCX_TABLE_IN_LDS. */
   ECCX_CT_GATHER = 1u << 10,       /* with ECCX_CT_SCAN, eccx_scalarmul_base: look the window's entry up by a cross-lane
                                       gather (ds_bpermute_b32 from the lane that holds the entry) instead of the scan of the
                                       whole window.  Still no memory address and no branch that depends on a digit; the

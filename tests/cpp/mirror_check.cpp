@@ -15,7 +15,7 @@ static const uint8_t GY[32] = {0x4f, 0xe3, 0x42, 0xe2, 0xfe, 0x1a, 0x7f, 0x9b, 0
 int main() {
   try {
     using C = eccx::P256r1;
-    eccx::Engine eng(0);
+    eccx::Engine eng(0, eccx::Secrecy::Public);
     const size_t n = 200;
     std::vector<uint8_t> k(n * C::SB, 0), g(n * 2 * C::FB);
     for (size_t i = 0; i < n; ++i) {
@@ -44,10 +44,9 @@ int main() {
     // secret-scalar mode (ECCX_CT_SCAN through the engine switch) gives the same points, and the
     // one-time costs can be paid up front
     {
-      eccx::Engine ct(0);
+      eccx::Engine ct(0, eccx::Secrecy::Secret);
       ct.prepare<C>(n);
       if (ct.device_bytes() == 0) { std::puts("FAIL: prepare left the context empty"); return 1; }
-      ct.secret_scalars(true);
       auto sbase = eccx::Points<C>::mul_base(ct, scalars);
       auto svar = eccx::on(ct, gen) * scalars;
       const auto& sb = sbase.to_affine();
