@@ -166,8 +166,11 @@ STEP_KERNELS = {
     ("x25519", "default"): [["k_x25519_ladder_unsat<eccx::ED25519U>"], ["k_batch_to_affine_unsat<eccx::ED25519U, 3,"]],
 }
 ED_STEP_KERNELS = {
-    ("var", "default"): [["k_ed_scalarmul_var_unsat<eccx::ED25519U, false>"], ["k_batch_to_affine_unsat<eccx::ED25519U, 2,"]],
-    ("dsm", "default"): [["k_ed_scalarmul_var_unsat<eccx::ED25519U, true>"], ["k_batch_to_affine_unsat<eccx::ED25519U, 2,"]],
+    ("var", "default"): [["k_ed_scalarmul_var_unsat<eccx::ED25519U, false, 5, false>", "k_ed_scalarmul_var_unsat<eccx::ED25519U, false>"],
+                         ["k_batch_to_affine_unsat<eccx::ED25519U, 2,"]],
+    ("var", "ct"): [["k_ed_scalarmul_var_unsat<eccx::ED25519U, false, 3, true>"], ["k_batch_to_affine_unsat<eccx::ED25519U, 2,"]],
+    ("dsm", "default"): [["k_ed_scalarmul_var_unsat<eccx::ED25519U, true, 5, false>", "k_ed_scalarmul_var_unsat<eccx::ED25519U, true>"],
+                         ["k_batch_to_affine_unsat<eccx::ED25519U, 2,"]],
     ("base", "default"): [["k_ed_scalarmul_base_unsat<eccx::ED25519U>"], ["k_batch_to_affine_unsat<eccx::ED25519U, 2,"]],
     ("base", "lds"): [["k_ed_scalarmul_base_lds6<eccx::ED25519U>"], ["k_batch_to_affine_unsat<eccx::ED25519U, 2,"]],
     ("base", "ct"): [["k_ed_scalarmul_base_ct<eccx::ED25519U, false>"], ["k_batch_to_affine_unsat<eccx::ED25519U, 2,"]],

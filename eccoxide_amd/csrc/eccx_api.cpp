@@ -171,22 +171,27 @@ int launch_var(eccx_ctx* ctx, const CurveOps* ops, size_t n, const uint8_t* d_sc
                bool glv = false, bool ct = false) {
   if (n == 0) return ECCX_OK;
   if (ct && ops->var_ct && !d_proj && d_points && !(kopts & (K_OUT_TABLE | K_BASE_IS_GENERATOR))) {
-    // secret scalars, Weierstrass: the affine-table ladder that reads every table row at every lookup and
-    // resolves its special cases by selects (kernels_coz.hpp, CT = true).  Units it marks -- from the BASE POINT
-    // alone: order <= 2^(WB-1), or not a curve point -- are skipped by the normalisation and redone by the
-    // reference-mirroring ladder with the scan (complete formulas), which writes their bytes itself.
+    // secret scalars: the windowed ladder that reads every table row at every lookup and resolves its special
+    // cases by selects (Weierstrass: kernels_coz.hpp, CT = true; edwards25519: k_ed_scalarmul_var_unsat, CT = true).
+    // Weierstrass units the kernel marks -- from the BASE POINT alone: order <= 2^(WB-1), or not a curve point --
+    // are skipped by the normalisation and redone by the reference-mirroring ladder with the scan (complete
+    // formulas), which writes their bytes itself; the complete Edwards formulas have no such units.
+    const bool ed = ops->info.edwards != 0;
     const int grid = ops->var_ct_grid(ctx->cus, n);
     const int grid2 = std::min(ops->var_grid ? ops->var_grid(ctx->cus, n) : grid_for(ctx, n), ctx->cus);
-    int rc = ensure_scratch(ctx, ops->coz_row_words, grid);
+    int rc = ensure_scratch(ctx, ed ? ops->info.row5_words : ops->coz_row_words, grid);
     if (rc) return rc;
-    rc = ensure_scratch(ctx, ops->info.row_words, grid2);
-    if (rc) return rc;
+    if (!ed) {
+      rc = ensure_scratch(ctx, ops->info.row_words, grid2);
+      if (rc) return rc;
+    }
     rc = ensure_rows(ctx, ops, n);
     if (rc) return rc;
     HIP_TRY(ctx, ops->var_ct(grid, s, n, d_scalars, d_points, ctx->jac, d_flags, ctx->scratch, kopts & ~K_CT_SCAN));
     HIP_TRY(ctx, ops->to_affine_var(norm_grid(ctx, n), s, n, ctx->jac, d_out, d_flags));
-    HIP_TRY(ctx, ops->var(grid2, s, n, d_scalars, d_points, d_out, d_flags, nullptr, ctx->scratch,
-                          (kopts & K_VALIDATE) | K_CT_SCAN | K_ONLY_MARKED));
+    if (!ed)
+      HIP_TRY(ctx, ops->var(grid2, s, n, d_scalars, d_points, d_out, d_flags, nullptr, ctx->scratch,
+                            (kopts & K_VALIDATE) | K_CT_SCAN | K_ONLY_MARKED));
     return ECCX_OK;
   }
   const bool fast = !mirror && ops->var_fast && !d_proj && !(kopts & K_OUT_TABLE);
@@ -686,12 +691,15 @@ int eccx_reserve(eccx_ctx* ctx, int curve, size_t max_n, uint32_t what) {
     if (!rc) rc = ensure_io(ctx, IO_B, max_n, &dummy);
     if (rc) return rc;
   }
-  if ((what & ECCX_PREP_CT) && ops->var_ct) {  // secret scalars: the scanning affine-table ladder + its fix-up
-    rc = ensure_scratch(ctx, ops->coz_row_words, ops->var_ct_grid(ctx->cus, max_n));
+  if ((what & ECCX_PREP_CT) && ops->var_ct) {  // secret scalars: the scanning ladder + (Weierstrass) its fix-up
+    const bool ed = ops->info.edwards != 0;
+    rc = ensure_scratch(ctx, ed ? ops->info.row5_words : ops->coz_row_words, ops->var_ct_grid(ctx->cus, max_n));
     if (rc) return rc;
-    const int grid2 = std::min(ops->var_grid ? ops->var_grid(ctx->cus, max_n) : grid_for(ctx, max_n), ctx->cus);
-    rc = ensure_scratch(ctx, ops->info.row_words, grid2);
-    if (rc) return rc;
+    if (!ed) {
+      const int grid2 = std::min(ops->var_grid ? ops->var_grid(ctx->cus, max_n) : grid_for(ctx, max_n), ctx->cus);
+      rc = ensure_scratch(ctx, ops->info.row_words, grid2);
+      if (rc) return rc;
+    }
   }
   // slab of the reference-mirroring ladder (also what ECCX_CT_SCAN runs on a curve without a scanning fast ladder)
   const bool mirror_slab = (what & ECCX_PREP_MIRROR) || ((what & ECCX_PREP_CT) && !ops->var_ct);

@@ -92,6 +92,17 @@ hipError_t compress_(int grid, hipStream_t s, size_t n, const uint8_t* xy, const
   hipLaunchKernelGGL((k_point_compress<ED25519, FORMAT_RFC8032>), dim3(grid), dim3(WG), 0, s, n, xy, nullptr, out);
   return hipGetLastError();
 }
+// secret scalars (ECCX_CT_SCAN), variable base: the windowed ladder with every table row read at every lookup
+hipError_t var_ct_(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint8_t* points, uint32_t* rows,
+                   uint8_t* flags, uint32_t* scratch, uint32_t opts) {
+  hipLaunchKernelGGL((k_ed_scalarmul_var_unsat<ED25519U, false, ECCX_CT_ED_VAR_BITS, true>), dim3(grid), dim3(WG), 0, s, n, scalars, points,
+                     rows, flags, scratch, opts, nullptr, nullptr);
+  return hipGetLastError();
+}
+int var_ct_grid_(int cus, size_t n) {
+  static const int occ = occupancy_per_cu(k_ed_scalarmul_var_unsat<ED25519U, false, ECCX_CT_ED_VAR_BITS, true>);
+  return persistent_grid(occ, cus, n);
+}
 // secret scalars (ECCX_CT_SCAN): signed windows, every entry of the window read (kernels_ct.hpp)
 hipError_t ct_convert_(hipStream_t s, size_t entries, const uint8_t* affine, uint32_t* table) {
   hipLaunchKernelGGL(k_ed_affine_to_niels_unsat<ED25519U>, dim3((unsigned)((entries + 127) / 128)), dim3(128), 0, s, entries, affine,
@@ -134,6 +145,8 @@ const CurveOps& ops_ED25519() {
     t.ctg_windows = ct_base_windows<ED25519U, true>();
     t.ctg_entries = ct_base_entries<ED25519U, true>();
     t.base_ctg = base_ctg_;
+    t.var_ct = var_ct_;
+    t.var_ct_grid = var_ct_grid_;
     return t;
   }();
   return o;

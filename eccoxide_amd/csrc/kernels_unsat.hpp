@@ -885,6 +885,29 @@ ECCX_DEV void ued_add(UEd<CU>& r, const UEd<CU>& p, const UEdCached<CU>& c, bool
   if constexpr (WITH_T) r.t = u_fit<1, 3>(u_mul(e, h));
 }
 
+// ued_add<CU, false> with the sign of the digit applied through the opaque selects (secret-scalar ladder)
+template <class CU>
+ECCX_DEV void ued_add_ct(UEd<CU>& r, const UEd<CU>& p, const UEdCached<CU>& c, bool neg) {
+  U<CU, 1, 3> ym, yp;
+  u_select_ct(ym, neg, c.yp, c.ym);
+  u_select_ct(yp, neg, c.ym, c.yp);
+  auto aa = u_mul(u_sub(p.y, p.x), ym);
+  auto bb = u_mul(u_add(p.y, p.x), yp);
+  auto cc = u_mul(p.t, c.t2d);
+  auto dd = u_mul(p.z, c.z2);
+  auto e = u_sub(bb, aa);
+  auto h = u_add(bb, aa);
+  auto dmc = u_fit<3, 8>(u_sub(dd, cc));
+  auto dpc = u_fit<3, 8>(u_add(dd, cc));
+  U<CU, 3, 8> fl, g;
+  u_select_ct(fl, neg, dpc, dmc);
+  u_select_ct(g, neg, dmc, dpc);
+  auto f = u_reduce(fl);
+  r.x = u_fit<1, 3>(u_mul(e, f));
+  r.y = u_fit<1, 3>(u_mul(g, h));
+  r.z = u_fit<1, 3>(u_mul(f, g));
+}
+
 template <class CU>
 ECCX_DEV void ued_cache(UEdCached<CU>& c, const UEd<CU>& p) {
   U<CU, 1, 2> d2;
@@ -924,7 +947,14 @@ ECCX_DEV void ued_row_load(UEdCached<CU>& c, const uint32_t* __restrict__ row) {
 // FUSED: the verify shape [u1]B + [u2]A ([u1]B - [u2]A with OPT_NEGATE_B; src/protocol/ed25519.rs:145)
 // in one pass: the ladder keeps T through its additions and the 16-bit comb of u1*B is accumulated
 // onto its result (base_scalars, utable as for k_ed_scalarmul_base_unsat).
-template <class CU, bool FUSED = false>
+// CT = true (ECCX_CT_SCAN): the same ladder for secret scalars -- WB-bit windows (narrower: every lookup reads ALL
+// 2^(WB-1) rows of the lane's table and keeps one by v_cndmask, so the table's traffic grows with its height), the
+// sign applied by selects, digit 0 = the neutral element the scan starts from.  The unified addition is complete
+// on this curve: there is nothing else to resolve, and no branch or address depends on the scalar.
+#ifndef ECCX_CT_ED_VAR_BITS
+#define ECCX_CT_ED_VAR_BITS 3
+#endif
+template <class CU, bool FUSED = false, int WB = 5, bool CT = false>
 __global__ void __launch_bounds__(WG, 4) k_ed_scalarmul_var_unsat(size_t n, const uint8_t* __restrict__ scalars,
                                                                   const uint8_t* __restrict__ points,
                                                                   uint32_t* __restrict__ rows_out, uint8_t* __restrict__ flags,
@@ -934,7 +964,9 @@ __global__ void __launch_bounds__(WG, 4) k_ed_scalarmul_var_unsat(size_t n, cons
   using CS = typename CU::Sat;
   constexpr int L = CS::L;
   constexpr int N = CU::N;
-  constexpr int NWIN = (8 * 32 + 1 + 4) / 5;
+  static_assert(!(CT && FUSED) && WB >= 2 && WB <= 5, "the secret-scalar form is the plain ladder");
+  constexpr int NWIN = (8 * 32 + 1 + WB - 1) / WB;
+  constexpr int TBL = 1 << (WB - 1);  // table rows 1 .. TBL (row 0: the neutral element)
   constexpr int RW = ED_VAR_ROW_WORDS;
   uint32_t* slab = scratch + ((size_t)blockIdx.x * FAST_TABLE_ROWS * WG + threadIdx.x) * (size_t)RW;
   auto row = [&](uint32_t e) { return slab + (size_t)e * WG * RW; };
@@ -988,35 +1020,24 @@ __global__ void __launch_bounds__(WG, 4) k_ed_scalarmul_var_unsat(size_t n, cons
     // table: T[2] = 2P, T[d+1] = T[d] + P
     UEd<CU> q;
     ued_dbl<CU, true>(q, p);
-    for (int d = 2; d <= 16; ++d) {
+    for (int d = 2; d <= TBL; ++d) {
       UEdCached<CU> c;
       ued_cache<CU>(c, q);
       ued_row_store<CU>(row(d), c);
-      if (d < 16) {
+      if (d < TBL) {
         UEd<CU> s;
         ued_add<CU, true>(s, q, c1, false);
         q = s;
       }
     }
     const uint8_t* __restrict__ k = scalars + idx * 32;
-    // Booth digit of window w: |digit| in 0..16 and its sign (big-endian scalar bytes)
-    auto booth = [&](int w, uint32_t& d, bool& neg) {
-      const int pos = 5 * w - 1 + 8;
-      const int bi = pos >> 3;
-      const uint32_t b0 = (bi >= 1 && bi <= 32) ? k[32 - bi] : 0u;
-      const uint32_t b1 = (bi + 1 <= 32) ? k[32 - bi - 1] : 0u;
-      const uint32_t w6 = ((b0 | (b1 << 8)) >> (pos & 7)) & 0x3fu;
-      const uint32_t s = ~((w6 >> 5) - 1u);
-      const uint32_t m = (((1u << 6) - w6 - 1u) & s) | (w6 & ~s);
-      d = (m >> 1) + (m & 1u);
-      neg = (s & 1u) != 0;
-    };
+    auto booth = [&](int w, uint32_t& d, bool& neg) { booth_digit<WB, 32>(k, w, d, neg); };
     // the neutral element
     u_set_zero(q.x); u_set_zero(q.y); u_set_zero(q.z); u_set_zero(q.t);
     q.y.v[0] = 1; q.z.v[0] = 1;
     for (int win = NWIN - 1; win >= 0; --win) {
       if (win != NWIN - 1) {
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < WB - 1; ++j) {
           UEd<CU> s;
           ued_dbl<CU, false>(s, q);
           q.x = s.x; q.y = s.y; q.z = s.z;
@@ -1029,9 +1050,26 @@ __global__ void __launch_bounds__(WG, 4) k_ed_scalarmul_var_unsat(size_t n, cons
       bool neg;
       booth(win, d, neg);
       UEdCached<CU> c;
-      ued_row_load<CU>(c, row(d));
       UEd<CU> s;
-      ued_add<CU, FUSED>(s, q, c, neg);  // the comb that follows needs T
+      if constexpr (CT) {
+        // select_from_table (curve25519.rs:862-869): every row read, the digit's row kept; no match = the neutral element
+        u_set_zero(c.ym); u_set_zero(c.yp); u_set_zero(c.z2); u_set_zero(c.t2d);
+        c.ym.v[0] = 1; c.yp.v[0] = 1; c.z2.v[0] = 2;
+#pragma unroll 2
+        for (int j = 1; j <= TBL; ++j) {
+          UEdCached<CU> r;
+          ued_row_load<CU>(r, row(j));
+          const uint64_t m = __builtin_amdgcn_uicmp(d, (uint32_t)j, 32 /* ICMP_EQ */);
+          u_cmov_ct(c.ym, m, r.ym);
+          u_cmov_ct(c.yp, m, r.yp);
+          u_cmov_ct(c.z2, m, r.z2);
+          u_cmov_ct(c.t2d, m, r.t2d);
+        }
+        ued_add_ct<CU>(s, q, c, neg);
+      } else {
+        ued_row_load<CU>(c, row(d));
+        ued_add<CU, FUSED>(s, q, c, neg);  // the comb that follows needs T
+      }
       q.x = s.x; q.y = s.y; q.z = s.z;
       if constexpr (FUSED) q.t = s.t;
     }

@@ -282,8 +282,6 @@ def test_ct_full_size_batches_match_the_default_kernels(engine, oracle, curve, l
     kb = ks.cpu().numpy().reshape(n, sb)[sample].tobytes()
     want = oracle.base(curve, kb, threads=16)
     assert oc.cpu().numpy().reshape(n, 2 * fb)[sample].tobytes() == want[0]
-    if curve == "ed25519":
-        return  # no scanning fast ladder for edwards25519 yet: ECCX_CT_SCAN variable base is the mirror kernel
     pts = ob  # k_i G: bases in the prime-order subgroup
     k2 = torch.from_numpy(W.random_scalars(curve, n, seed=972)).to(dev)
     ov, fv = engine.scalarmul_var_t(curve, k2, pts)
