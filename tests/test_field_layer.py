@@ -236,6 +236,11 @@ def test_division_step_inversion(fc, curve):
     vals += [(1 << k) - 1 for k in range(2, p.bit_length() - 1, 31)]
     vals += [p - (1 << k) for k in range(0, p.bit_length() - 2, 37)]
     vals += [rng.randrange(1, p) for _ in range(300)]
+    if p.bit_length() <= 256:
+        # the two fields that run 20 batches (600 half-delta steps, 590 proven): feed the kernel the inputs that
+        # need the MOST steps in the Python model of the same rule, so the budget is exercised where it is tightest
+        cand = [rng.randrange(1, p) for _ in range(3000)] + [p - 1, (p + 1) // 2, (p - 1) // 2, (1 << 254) - 1]
+        vals += sorted(cand, key=lambda v: _hd_divsteps_needed(p, v, 600), reverse=True)[:24]
     vals = [v % p for v in vals]
     rows = [[(v >> (32 * i)) & 0xFFFFFFFF if i < L else 0 for i in range(N)] for v in vals]
     out = fc.run(curve, OP_INVERT, rows, rows)

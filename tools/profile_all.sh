@@ -4,11 +4,11 @@
 # usage (inside gpurun): bash tools/profile_all.sh r02 [workload-spec ...]
 #   a workload-spec is "name" or "name:variant"; default: every workload of bench.py
 set -o pipefail
-ROUND=${1:-r02}; shift
+ROUND=${1:-r03}; shift
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 SPECS=("$@")
 if [ ${#SPECS[@]} -eq 0 ]; then
-  SPECS=("p256r1_var_2^20" "p384r1_var_2^19" "p521r1_var_2^19" "bls12_381_g1_var_2^20" "ed25519_var_2^20"
+  SPECS=("p256r1_var_2^20" "p384r1_var_2^19" "p521r1_var_2^19" "bls12_381_g1_var_2^20" "bls12_381_g1_var_2^20:glv" "ed25519_var_2^20" "p256r1_var_2^20:ct" "ed25519_var_2^20:ct" "p256r1_base_2^20:ct" "p256r1_base_2^20:ctg" "ed25519_base_2^20:ct" "ed25519_base_2^20:ctg"
          "p256r1_verify_2^20" "ed25519_base_2^20" "ed25519_base_2^20:lds" "p256r1_base_2^20" "x25519_2^20")
 fi
 for spec in "${SPECS[@]}"; do

@@ -80,12 +80,20 @@ def main():
             # the bases are multiples of G, so the endomorphism ladder must agree with the co-Z ladder
             v_glv, vf_glv = eng.scalarmul_var_t(curve, k2, b_def, assume_subgroup=True)
             assert torch.equal(v_glv, v_def) and torch.equal(vf_glv, vf_def), ("glv", curve, n, rounds)
-        if rounds % 6 == 0:
-            # ECCX_CT_SCAN: the mirror kernels with the scanning lookups
+        if rounds % 3 == 0:
+            # ECCX_CT_SCAN: the secret-scalar kernels (scanning ladder, scanning comb, lane-gather comb), and every
+            # sixth round the reference-mirroring kernels with the scan
             v_ct, vf_ct = eng.scalarmul_var_t(curve, k2, b_def, ct_scan=True)
             assert torch.equal(v_ct, v_def) and torch.equal(vf_ct, vf_def), ("ct var", curve, n, rounds)
             b_ct, f_ct = eng.scalarmul_base_t(curve, k1, ct_scan=True)
             assert torch.equal(b_ct, b_mir) and torch.equal(f_ct, f_mir), ("ct base", curve, n, rounds)
+            b_cg, f_cg = eng.scalarmul_base_t(curve, k1, ct_gather=True)
+            assert torch.equal(b_cg, b_mir) and torch.equal(f_cg, f_mir), ("ct gather base", curve, n, rounds)
+            if rounds % 6 == 0:
+                v_cm, vf_cm = eng.scalarmul_var_t(curve, k2, b_def, ct_scan=True, mirror=True)
+                assert torch.equal(v_cm, v_def) and torch.equal(vf_cm, vf_def), ("ct mirror var", curve, n, rounds)
+                b_cm, f_cm = eng.scalarmul_base_t(curve, k1, ct_scan=True, mirror=True)
+                assert torch.equal(b_cm, b_mir) and torch.equal(f_cm, f_mir), ("ct mirror base", curve, n, rounds)
         # fused double-scalar against comb + ladder + complete addition
         for subtract in (False, True):
             d_out, d_fl = eng.double_scalarmul_t(curve, k1, k2, b_def, subtract=subtract)
