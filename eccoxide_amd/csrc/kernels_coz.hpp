@@ -140,6 +140,21 @@ ECCX_DEV void u2_load(U<CU, 1, 3>& x, U<CU, 1, 3>& y, const uint32_t* __restrict
   for (int i = 0; i < N; ++i) { x.v[i] = w[i]; y.v[i] = w[N + i]; }
 }
 
+// the two coordinates of a table entry as a row of their own (the secret-scalar ladder's compact table)
+template <class CU>
+constexpr int urow2_words() { return ((2 * CU::N + 3) / 4) * 4; }
+template <class CU>
+ECCX_DEV void u2_store(uint32_t* __restrict__ row, const U<CU, 1, 3>& x, const U<CU, 1, 3>& y) {
+  constexpr int N = CU::N;
+  constexpr int W = urow2_words<CU>();
+  uint32_t w[W];
+#pragma unroll
+  for (int i = 0; i < W; ++i) w[i] = i < N ? x.v[i] : (i < 2 * N ? y.v[i - N] : 0u);
+  uint4* dst = reinterpret_cast<uint4*>(row);
+#pragma unroll
+  for (int i = 0; i < W / 4; ++i) dst[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+
 // r = p + (x2, +-y2, 1)
 template <class CU>
 ECCX_DEV void ujac_madd_signed(UJac<CU>& r, bool& h_zero, bool& r_zero, const UJac<CU>& p,
@@ -336,6 +351,14 @@ __global__ void __launch_bounds__(WG, (coz_occupancy<CU, GLV>())) k_scalarmul_co
   using T = U<CU, 1, 3>;
   uint32_t* slab = scratch + ((size_t)blockIdx.x * FAST_TABLE_ROWS * WG + threadIdx.x) * (size_t)WR;
   auto row = [&](uint32_t e) { return slab + (size_t)e * WG * WR; };
+  // Secret-scalar form: the finished table (x, y per entry) is written a second time as rows of 2 N words in the part of
+  // the slab the build does not use (rows TBL + 1 .. 16): every lookup reads ALL of it, so its rows are packed -- a
+  // wavefront's reads of one entry are then one contiguous run (the 3-column build rows leave a quarter of every
+  // 128-byte line unused: 67 GB per 2^20 P-256 units against 44 GB).
+  constexpr int WC = urow2_words<CU>();
+  static_assert(!CT || (size_t)TBL * WC <= (size_t)(FAST_TABLE_ROWS - 1 - TBL) * WR, "the compact table must fit the free rows");
+  uint32_t* cslab = scratch + ((size_t)blockIdx.x * FAST_TABLE_ROWS + (TBL + 1)) * WG * (size_t)WR + (size_t)threadIdx.x * WC;
+  auto crow = [&](uint32_t e) { return cslab + (size_t)(e - 1) * WG * WC; };
   for (size_t base = (size_t)blockIdx.x * WG; base < n; base += (size_t)gridDim.x * WG) {
     const size_t gid = base + threadIdx.x;
     const bool active = gid < n;
@@ -425,6 +448,7 @@ __global__ void __launch_bounds__(WG, (coz_occupancy<CU, GLV>())) k_scalarmul_co
       T lam = one, next = ratio;
       if constexpr (ISO) {
         if constexpr (GLV) u3_store<CU>(row(TBL), tx, ty, u_fit<1, 3>(u_mul_k<CU>(tx, CU::BETA)));
+        if constexpr (CT) u2_store<CU>(crow(TBL), tx, ty);  // the top entry is affine on E' as it stands
       } else {
         // 1 / zeta (zeta = 0 only for degenerate units, which are redone anyway: the inverse of 0 is 0)
         Fe<L> c;
@@ -433,7 +457,9 @@ __global__ void __launch_bounds__(WG, (coz_occupancy<CU, GLV>())) k_scalarmul_co
         lam = u_as<1, 3>(u_to_mont<CU>(c));
         const T l2 = u_fit<1, 3>(u_sqr(lam));
         const T l3 = u_fit<1, 3>(u_mul(l2, lam));
-        u3_store<CU>(row(TBL), u_fit<1, 3>(u_mul(tx, l2)), u_fit<1, 3>(u_mul(ty, l3)), one);
+        const T xt = u_fit<1, 3>(u_mul(tx, l2)), yt = u_fit<1, 3>(u_mul(ty, l3));
+        if constexpr (CT) u2_store<CU>(crow(TBL), xt, yt);
+        else u3_store<CU>(row(TBL), xt, yt, one);
       }
       for (int d = TBL - 1; d >= 1; --d) {
         lam = u_fit<1, 3>(u_mul(lam, next));
@@ -444,6 +470,7 @@ __global__ void __launch_bounds__(WG, (coz_occupancy<CU, GLV>())) k_scalarmul_co
         const T xs = u_fit<1, 3>(u_mul(x, l2));
         const T ys = u_fit<1, 3>(u_mul(y, l3));
         if constexpr (GLV) u3_store<CU>(row(d), xs, ys, u_fit<1, 3>(u_mul_k<CU>(xs, CU::BETA)));
+        else if constexpr (CT) u2_store<CU>(crow(d), xs, ys);
         else u3_store<CU>(row(d), xs, ys, one);
       }
       if constexpr (ISO) {  // zeta = Z_16 / Z_1: the product of all ratios
@@ -465,7 +492,7 @@ __global__ void __launch_bounds__(WG, (coz_occupancy<CU, GLV>())) k_scalarmul_co
 #pragma unroll 2
         for (int j = 1; j <= TBL; ++j) {
           T cx, cy;
-          u2_load<CU>(cx, cy, row(j));
+          u2_load<CU>(cx, cy, crow(j));
           const uint64_t m = __builtin_amdgcn_uicmp(d, (uint32_t)j, 32 /* ICMP_EQ */);
           u_cmov_ct(ex, m, cx);
           u_cmov_ct(ey, m, cy);

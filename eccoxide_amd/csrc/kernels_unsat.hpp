@@ -885,6 +885,31 @@ ECCX_DEV void ued_add(UEd<CU>& r, const UEd<CU>& p, const UEdCached<CU>& c, bool
   if constexpr (WITH_T) r.t = u_fit<1, 3>(u_mul(e, h));
 }
 
+// r = p + (+-)(the table point with Z = 1 given as y - x, y + x, 2d x y): 6 products, T not produced; the sign of the
+// digit is applied through the opaque selects (secret-scalar ladder over its normalised table)
+template <class CU>
+ECCX_DEV void ued_add_niels_ct(UEd<CU>& r, const UEd<CU>& p, const U<CU, 1, 3>& ym_, const U<CU, 1, 3>& yp_, const U<CU, 1, 3>& t2d,
+                               bool neg) {
+  U<CU, 1, 3> ym, yp;
+  u_select_ct(ym, neg, yp_, ym_);
+  u_select_ct(yp, neg, ym_, yp_);
+  auto aa = u_mul(u_sub(p.y, p.x), ym);
+  auto bb = u_mul(u_add(p.y, p.x), yp);
+  auto cc = u_mul(p.t, t2d);
+  auto dd = u_add(p.z, p.z);
+  auto e = u_sub(bb, aa);
+  auto h = u_add(bb, aa);
+  auto dmc = u_fit<3, 8>(u_sub(dd, cc));
+  auto dpc = u_fit<3, 8>(u_add(dd, cc));
+  U<CU, 3, 8> fl, g;
+  u_select_ct(fl, neg, dpc, dmc);
+  u_select_ct(g, neg, dmc, dpc);
+  auto f = u_reduce(fl);
+  r.x = u_fit<1, 3>(u_mul(e, f));
+  r.y = u_fit<1, 3>(u_mul(g, h));
+  r.z = u_fit<1, 3>(u_mul(f, g));
+}
+
 // ued_add<CU, false> with the sign of the digit applied through the opaque selects (secret-scalar ladder)
 template <class CU>
 ECCX_DEV void ued_add_ct(UEd<CU>& r, const UEd<CU>& p, const UEdCached<CU>& c, bool neg) {
@@ -1030,6 +1055,55 @@ __global__ void __launch_bounds__(WG, 4) k_ed_scalarmul_var_unsat(size_t n, cons
         q = s;
       }
     }
+    // Secret-scalar form: every lookup reads the WHOLE table, so the table is made small -- each entry brought to Z = 1
+    // (one inversion per unit by division steps, shared by Montgomery's trick) and written as (y - x, y + x, 2d x y), 28
+    // words, into the rows of the slab the build leaves free: 112 B per entry instead of 144, and an addition of 6
+    // products instead of 7.
+    constexpr int NW = ((3 * N + 3) / 4) * 4;
+    static_assert(!CT || (size_t)TBL * NW <= (size_t)(FAST_TABLE_ROWS - 1 - TBL) * RW, "the compact table must fit the free rows");
+    uint32_t* cslab = scratch + ((size_t)blockIdx.x * FAST_TABLE_ROWS + (TBL + 1)) * WG * (size_t)RW + (size_t)threadIdx.x * NW;
+    auto crow = [&](uint32_t e) { return cslab + (size_t)(e - 1) * WG * NW; };
+    if constexpr (CT) {
+      auto store3 = [&](uint32_t e, const U<CU, 1, 3>& a, const U<CU, 1, 3>& b, const U<CU, 1, 3>& c) {
+        uint32_t w[NW];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) w[i] = i < N ? a.v[i] : (i < 2 * N ? b.v[i - N] : (i < 3 * N ? c.v[i - 2 * N] : 0u));
+        uint4* dst = reinterpret_cast<uint4*>(crow(e));
+#pragma unroll
+        for (int i = 0; i < NW / 4; ++i) dst[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+      };
+      store3(1, c1.ym, c1.yp, c1.t2d);  // P itself: Z = 1 already
+      if constexpr (TBL >= 2) {
+        U<CU, 1, 3> pre[TBL];  // pre[d] = z2_2 * ... * z2_d (z2 = 2 Z)
+#pragma unroll
+        for (int d = 2; d <= TBL; ++d) {
+          UEdCached<CU> c;
+          ued_row_load<CU>(c, row(d));
+          pre[d - 1] = d == 2 ? c.z2 : u_fit<1, 3>(u_mul(pre[d - 2], c.z2));
+        }
+        U<CU, 1, 3> inv;
+        {
+          Fe<L> cz;
+          u_to_canonical<CU>(cz, pre[TBL - 1]);
+          fe_inv_gcd<CS>(cz, cz);
+          inv = u_reduce(u_as<1, 3>(u_from_sat<CU>(cz)));
+        }
+#pragma unroll
+        for (int d = TBL; d >= 2; --d) {
+          UEdCached<CU> c;
+          ued_row_load<CU>(c, row(d));
+          U<CU, 1, 3> zi;  // 1 / (2 Z_d)
+          if (d > 2) {
+            zi = u_fit<1, 3>(u_mul(inv, pre[d - 2]));
+            inv = u_fit<1, 3>(u_mul(inv, c.z2));
+          } else {
+            zi = inv;
+          }
+          const auto w2 = u_reduce(u_add(zi, zi));  // 1 / Z_d
+          store3((uint32_t)d, u_fit<1, 3>(u_mul(c.ym, w2)), u_fit<1, 3>(u_mul(c.yp, w2)), u_fit<1, 3>(u_mul(c.t2d, w2)));
+        }
+      }
+    }
     const uint8_t* __restrict__ k = scalars + idx * 32;
     auto booth = [&](int w, uint32_t& d, bool& neg) { booth_digit<WB, 32>(k, w, d, neg); };
     // the neutral element
@@ -1053,19 +1127,27 @@ __global__ void __launch_bounds__(WG, 4) k_ed_scalarmul_var_unsat(size_t n, cons
       UEd<CU> s;
       if constexpr (CT) {
         // select_from_table (curve25519.rs:862-869): every row read, the digit's row kept; no match = the neutral element
-        u_set_zero(c.ym); u_set_zero(c.yp); u_set_zero(c.z2); u_set_zero(c.t2d);
-        c.ym.v[0] = 1; c.yp.v[0] = 1; c.z2.v[0] = 2;
+        U<CU, 1, 3> sym, syp, st;
+        u_set_zero(sym); u_set_zero(syp); u_set_zero(st);
+        sym.v[0] = 1; syp.v[0] = 1;
 #pragma unroll 2
         for (int j = 1; j <= TBL; ++j) {
-          UEdCached<CU> r;
-          ued_row_load<CU>(r, row(j));
+          uint32_t w[NW];
+          const uint4* src = reinterpret_cast<const uint4*>(crow(j));
+#pragma unroll
+          for (int i = 0; i < NW / 4; ++i) {
+            const uint4 v4 = src[i];
+            w[4 * i] = v4.x; w[4 * i + 1] = v4.y; w[4 * i + 2] = v4.z; w[4 * i + 3] = v4.w;
+          }
+          U<CU, 1, 3> rym, ryp, rt;
+#pragma unroll
+          for (int i = 0; i < N; ++i) { rym.v[i] = w[i]; ryp.v[i] = w[N + i]; rt.v[i] = w[2 * N + i]; }
           const uint64_t m = __builtin_amdgcn_uicmp(d, (uint32_t)j, 32 /* ICMP_EQ */);
-          u_cmov_ct(c.ym, m, r.ym);
-          u_cmov_ct(c.yp, m, r.yp);
-          u_cmov_ct(c.z2, m, r.z2);
-          u_cmov_ct(c.t2d, m, r.t2d);
+          u_cmov_ct(sym, m, rym);
+          u_cmov_ct(syp, m, ryp);
+          u_cmov_ct(st, m, rt);
         }
-        ued_add_ct<CU>(s, q, c, neg);
+        ued_add_niels_ct<CU>(s, q, sym, syp, st, neg);
       } else {
         ued_row_load<CU>(c, row(d));
         ued_add<CU, FUSED>(s, q, c, neg);  // the comb that follows needs T
