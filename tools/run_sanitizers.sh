@@ -4,10 +4,10 @@
 #      oracle's own CPU tests (golden vectors, RFC 7748, gloo sharding through the oracle);
 #   2. the C ABI's host code (eccoxide_amd/csrc/eccx_api.cpp, host side only: -fno-gpu-sanitize)
 #      under the same sanitizers, driven by the argument / error-path tests that need no device.
-# usage: bash tools/run_sanitizers.sh [outfile]     (writes a short report, default profiles/r02_sanitizers.txt)
+# usage: bash tools/run_sanitizers.sh [outfile]     (writes a short report, default profiles/r03_sanitizers.txt)
 set -o pipefail
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-OUT=${1:-$ROOT/profiles/r02_sanitizers.txt}
+OUT=${1:-$ROOT/profiles/r03_sanitizers.txt}
 cd "$ROOT"
 ASAN=$(gcc -print-file-name=libasan.so); UBSAN=$(gcc -print-file-name=libubsan.so)
 {
