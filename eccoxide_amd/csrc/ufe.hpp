@@ -735,10 +735,23 @@ ECCX_DEV auto u_neg(const U<C, K2, V2>& b) {
   }
 }
 
+#ifndef ECCX_SELECT_E64
+#define ECCX_SELECT_E64 0  // 1: A/B -- every u_select through v_cndmask_b32_e64 with an SGPR-pair mask (VCC-masked selects issue 3-4x slower)
+#endif
 template <class C, int K, int V>
 ECCX_DEV void u_select(U<C, K, V>& r, bool take_a, const U<C, K, V>& a, const U<C, K, V>& b) {
+#if ECCX_SELECT_E64
+  const uint64_t m = __builtin_amdgcn_uicmp((uint32_t)take_a, 1u, 32);
+#pragma unroll
+  for (int i = 0; i < C::N; ++i) {
+    uint32_t t = b.v[i];
+    asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(t) : "v"(a.v[i]), "s"(m));
+    r.v[i] = t;
+  }
+#else
 #pragma unroll
   for (int i = 0; i < C::N; ++i) r.v[i] = take_a ? a.v[i] : b.v[i];
+#endif
 }
 
 template <class C, int K, int V>

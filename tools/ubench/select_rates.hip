@@ -11,7 +11,8 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); return 1; } } while (0)
 
 constexpr int GROUPS = 8;
-enum Pat { SMOV_CND4, VCMP_CND4, VCMP_CND8, CND4_E64, BFI4, VCMP_CND1, BPERM_ID, BPERM_RANDOM, BPERM_SAME, BPERM_FOLD };
+enum Pat { SMOV_CND4, VCMP_CND4, VCMP_CND8, CND4_E64, BFI4, VCMP_CND1, BPERM_ID, BPERM_RANDOM, BPERM_SAME, BPERM_FOLD,
+           EXEC_MOV32_DIGIT, EXEC_MOV32_FULL, EXEC_MOV32_LOWER, EXEC_MOV32_ZERO, EXEC_MOV64_DIGIT, EXEC_MOV64_FULL, EXEC_MOV64_LOWER, EXEC_MOV64_ZERO };
 
 template <int P>
 __global__ void __launch_bounds__(256) k_sel(uint32_t* out, uint64_t* clocks, int iters, uint32_t seed) {
@@ -61,6 +62,26 @@ __global__ void __launch_bounds__(256) k_sel(uint32_t* out, uint64_t* clocks, in
                      : "v"(a[g][0]), "v"(a[g][1]), "v"(a[g][2]), "v"(a[g][3]), "v"(m));
       } else if constexpr (P == VCMP_CND1) {  // a quarter of an op
         asm volatile("v_cmp_eq_u32_e32 vcc, %3, %2\n\tv_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(o[g][0]) : "v"(a[g][0]), "v"(d), "s"(j) : "vcc");
+      } else if constexpr (P >= EXEC_MOV32_DIGIT) {
+        // the select as an EXEC-masked move: exec = lane mask, v_mov, exec = all.  A VALU instruction issues whatever EXEC
+        // holds -- if the hardware skipped a half-wave whose lanes are all masked off, the time would depend on the
+        // mask: four masks (the digit's, all lanes, the lower half only, none) must cost the same for this to be usable.
+        uint64_t m;
+        if constexpr (P == EXEC_MOV32_DIGIT || P == EXEC_MOV64_DIGIT) m = __builtin_amdgcn_uicmp(d, j, 32);
+        else if constexpr (P == EXEC_MOV32_FULL || P == EXEC_MOV64_FULL) m = ~0ull;
+        else if constexpr (P == EXEC_MOV32_LOWER || P == EXEC_MOV64_LOWER) m = 0xffffffffull;
+        else m = (uint64_t)(j >> 6);  // zero, but not a compile-time constant
+        if constexpr (P < EXEC_MOV64_DIGIT) {
+          asm volatile("s_mov_b64 exec, %8\n\tv_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7\n\ts_mov_b64 exec, -1"
+                       : "+v"(o[g][0]), "+v"(o[g][1]), "+v"(o[g][2]), "+v"(o[g][3])
+                       : "v"(a[g][0]), "v"(a[g][1]), "v"(a[g][2]), "v"(a[g][3]), "s"(m));
+        } else {
+          uint64_t o0 = ((uint64_t)o[g][1] << 32) | o[g][0], o1 = ((uint64_t)o[g][3] << 32) | o[g][2];
+          const uint64_t a0 = ((uint64_t)a[g][1] << 32) | a[g][0], a1 = ((uint64_t)a[g][3] << 32) | a[g][2];
+          asm volatile("s_mov_b64 exec, %4\n\tv_mov_b64 %0, %2\n\tv_mov_b64 %1, %3\n\ts_mov_b64 exec, -1"
+                       : "+v"(o0), "+v"(o1) : "v"(a0), "v"(a1), "s"(m));
+          o[g][0] = (uint32_t)o0; o[g][1] = (uint32_t)(o0 >> 32); o[g][2] = (uint32_t)o1; o[g][3] = (uint32_t)(o1 >> 32);
+        }
       } else {
         // ds_bpermute_b32 with four index patterns (one op = 4 permutes of one word): is its time the same whatever
         // the lanes ask for?  identity; a random source lane in 0..31; every lane the same source; sources j and
@@ -129,6 +150,14 @@ int main() {
     run<CND4_E64>("4 v_cndmask_e64, SGPR-pair mask", 1, dout, dclk, blocks, iters);
     run<BFI4>("4 v_bfi_b32, VGPR mask", 1, dout, dclk, blocks, iters);
     run<VCMP_CND1>("v_cmp_e32 + 1 v_cndmask_e32 (per 4 words)", 0.25, dout, dclk, blocks, iters);
+    run<EXEC_MOV32_DIGIT>("exec = digit mask, 4 v_mov_b32", 1, dout, dclk, blocks, iters);
+    run<EXEC_MOV32_FULL>("exec = all lanes, 4 v_mov_b32", 1, dout, dclk, blocks, iters);
+    run<EXEC_MOV32_LOWER>("exec = lower half only, 4 v_mov_b32", 1, dout, dclk, blocks, iters);
+    run<EXEC_MOV32_ZERO>("exec = no lane, 4 v_mov_b32", 1, dout, dclk, blocks, iters);
+    run<EXEC_MOV64_DIGIT>("exec = digit mask, 2 v_mov_b64", 1, dout, dclk, blocks, iters);
+    run<EXEC_MOV64_FULL>("exec = all lanes, 2 v_mov_b64", 1, dout, dclk, blocks, iters);
+    run<EXEC_MOV64_LOWER>("exec = lower half only, 2 v_mov_b64", 1, dout, dclk, blocks, iters);
+    run<EXEC_MOV64_ZERO>("exec = no lane, 2 v_mov_b64", 1, dout, dclk, blocks, iters);
     run<BPERM_ID>("4 ds_bpermute_b32, identity", 1, dout, dclk, blocks, iters / 4);
     run<BPERM_RANDOM>("4 ds_bpermute_b32, random source in 0..31", 1, dout, dclk, blocks, iters / 4);
     run<BPERM_SAME>("4 ds_bpermute_b32, every lane the same source", 1, dout, dclk, blocks, iters / 4);
