@@ -44,7 +44,7 @@ def _sat(muls, pairs_per_mul):
     return {"pair": muls * pairs_per_mul, "mad": 0}
 
 
-def _var_unsat(n, nz, sb, a0, inv, sat_pairs, mont=True, norm_u=8, glv_bits=0, merged_y3=False, inv30=(0, 0, 0)):
+def _var_unsat(n, nz, sb, a0, inv, sat_pairs, mont=True, norm_u=8, glv_bits=0, merged_y3=False, inv30=(0, 0, 0), wb=5, full_windows=0):
     """v_mad_u64_u32 / v_mad_i64_i32 per unit of the default variable-base path (kernels_coz.hpp in front
     of kernels_unsat.hpp): n limbs of 28/29 bits, one mad per limb product.  A product is n*n mads, a
     square n(n+1)/2, a Montgomery reduction n*nz (nz = non-zero reduction digits per Montgomery factor:
@@ -63,6 +63,9 @@ def _var_unsat(n, nz, sb, a0, inv, sat_pairs, mont=True, norm_u=8, glv_bits=0, m
     a = 0 (BLS12-381): doubling 3 products + 4 squares with 6 reductions, additions with 10 (Y3 merged);
     glv_bits > 0: the endomorphism form, two half-length scalars, 2 additions per window and one more
     product per entry (beta x).
+    wb: window width (5 default; 4 for the secret-scalar form, whose table has 2^(wb-1) entries);
+    full_windows: the bottom windows of the secret-scalar form that also compute 2 * entry from its affine
+    coordinates (2 products + 4 squares; kernels_coz.hpp coz_full_windows()).
     (inv, sat_pairs and norm_u are kept for reference only)"""
     prod, sq, red = n * n, n * (n + 1) // 2, n * nz
 
@@ -72,11 +75,12 @@ def _var_unsat(n, nz, sb, a0, inv, sat_pairs, mont=True, norm_u=8, glv_bits=0, m
     conv = cost(5, 0) if mont else 0                     # 2 products into the working form, 3 out of it
     norm = cost(9, 1)                                    # normalisation kernel: 7 products + 1 square + 2 conversions out
     bits = glv_bits if glv_bits else 8 * sb
-    nwin = (bits + 1 + 4) // 5
+    nwin = (bits + 1 + wb - 1) // wb
+    tbl = 1 << (wb - 1)
     per_entry = cost(4, 1) + (cost(1, 0) if glv_bits else 0)
     if a0:
         dbl, madd = cost(3, 4, 6), cost(8, 3, 10)        # doubling: X*B, E*t, Y*Z + X^2, Y^2, E^2 and -2(2B)^2 as a square; 6 reductions
-        build = cost(2, 4) + 14 * cost(4, 2) + 15 * per_entry + (cost(1, 0) if glv_bits else 0)   # (+ beta x of entry 16)
+        build = cost(2, 4) + (tbl - 2) * cost(4, 2) + (tbl - 1) * per_entry + (cost(1, 0) if glv_bits else 0)   # (+ beta x of the top entry)
         tail = cost(1, 0)                                # Z *= zeta
     else:
         dbl, madd = cost(4, 4), cost(8, 3)
@@ -84,9 +88,9 @@ def _var_unsat(n, nz, sb, a0, inv, sat_pairs, mont=True, norm_u=8, glv_bits=0, m
             dbl, madd = cost(4, 4, 7), cost(8, 3, 10)
         n30, nz30, batches = inv30
         inversion = batches * (8 * n30 + 2 * nz30) + (cost(2, 0) if mont else 0)
-        build = cost(2, 4) + 14 * cost(5, 2) + inversion + cost(3, 1) + 15 * per_entry
+        build = cost(2, 4) + (tbl - 2) * cost(5, 2) + inversion + cost(3, 1) + (tbl - 1) * per_entry
         tail = 0
-    total = build + (nwin - 1) * 5 * dbl + (nwin * (2 if glv_bits else 1) - 1) * madd + tail
+    total = build + (nwin - 1) * wb * dbl + (nwin * (2 if glv_bits else 1) - 1) * madd + tail + full_windows * cost(2, 4)
     return {"mad": total + conv + norm, "pair": 0}
 
 
@@ -135,8 +139,45 @@ WORKLOADS = {
     "p521r1_var_2^19": ("p521r1", "var", 1 << 19, 330, _var_unsat(18, 0, 66, 0, 780, 17 * 17, mont=False, inv30=(18, 18, 51))),
     "bls12_381_g1_var_2^20": ("bls12_381_g1", "var", 1 << 20, 224, _var_unsat(14, 14, 32, 1, 570, 2 * 12 * 12)),
 }
-# multiplier instructions of the non-default variants that have a count of their own
-VARIANT_MULT = {("bls12_381_g1_var_2^20", "glv"): _var_unsat(14, 14, 32, 1, 570, 0, glv_bits=129)}
+def _base_ct(n, nz, sb, nbits, w, merged_y3=False):
+    """Secret-scalar fixed base (kernels_ct.hpp k_scalarmul_base_ct): ceil((8 SB + 1) / w) signed windows, EVERY one a
+    mixed XYZZ addition (8 products + 2 squares; Y3 in one reduction where the field merges it), the top
+    ct_unsafe_windows() also 2 * entry from affine coordinates (4 products + 3 squares), 2 products to the Jacobian row,
+    then the normalisation as in _var_unsat."""
+    prod, sq, red = n * n, n * (n + 1) // 2, n * nz
+
+    def cost(p, s, r=None):
+        return p * prod + s * sq + (p + s if r is None else r) * red
+
+    nwin = (8 * sb + 1 + w - 1) // w
+    unsafe = nwin - (nbits + w - 1) // w + 1
+    return {"mad": nwin * cost(8, 2, 9 if merged_y3 else None) + unsafe * cost(4, 3) + cost(2, 0) + cost(9, 1), "pair": 0}
+
+
+def _ed_base_ct(w):
+    """edwards25519 fixed base, secret scalars: ceil(257 / w) complete additions of 7 products (81 + 9 mads), the
+    normalisation (5 products)"""
+    return {"mad": (((257 + w - 1) // w) * 7 + 5) * 90, "pair": 0}
+
+
+# multiplier instructions of the non-default variants that have a count of their own.  Window widths as compiled:
+# ECCX_CT_VAR_BITS 4, ECCX_CT_ED_VAR_BITS 3, ECCX_CT_BASE_BITS 6 (edwards25519: 5), ECCX_CT_GATHER_BITS 7.
+VARIANT_MULT = {
+    ("bls12_381_g1_var_2^20", "glv"): _var_unsat(14, 14, 32, 1, 570, 0, glv_bits=129),
+    ("p256r1_var_2^20", "ct"): _var_unsat(9, 4, 32, 0, 383, 0, inv30=(9, 7, 20), wb=4, full_windows=1),
+    ("p384r1_var_2^19", "ct"): _var_unsat(14, 4, 48, 0, 575, 0, merged_y3=True, inv30=(13, 12, 37), wb=4, full_windows=1),
+    ("p521r1_var_2^19", "ct"): _var_unsat(18, 0, 66, 0, 780, 0, mont=False, inv30=(18, 18, 51), wb=4, full_windows=3),
+    ("bls12_381_g1_var_2^20", "ct"): _var_unsat(14, 14, 32, 1, 570, 0, wb=4, full_windows=64),
+    # edwards25519, 86 signed 3-bit windows: 85 x 3 doublings (4 squares + 3 products, the last of a window + 1), 86
+    # additions of 6 products, the 4-entry table (1 doubling, 2 additions of 8, 4 x 2d T, to Z = 1: 15 products
+    # + one division-step inversion), the normalisation (5 products)
+    ("ed25519_var_2^20", "ct"): {"mad": (85 * 12 + 4) * 54 + (85 * 10 + 86 * 6 + 1 + 4 + 16 + 4 + 15 + 5) * 90 + 20 * (8 * 9 + 2), "pair": 0},
+    ("p256r1_base_2^20", "ct"): _base_ct(9, 4, 32, 256, 6), ("p256r1_base_2^20", "ctg"): _base_ct(9, 4, 32, 256, 7),
+    ("p384r1_base_2^19", "ct"): _base_ct(14, 4, 48, 384, 6, True), ("p384r1_base_2^19", "ctg"): _base_ct(14, 4, 48, 384, 7, True),
+    ("p521r1_base_2^19", "ct"): _base_ct(18, 0, 66, 521, 6), ("p521r1_base_2^19", "ctg"): _base_ct(18, 0, 66, 521, 7),
+    ("bls12_381_g1_base_2^20", "ct"): _base_ct(14, 14, 32, 255, 6, True), ("bls12_381_g1_base_2^20", "ctg"): _base_ct(14, 14, 32, 255, 7, True),
+    ("ed25519_base_2^20", "ct"): _ed_base_ct(5), ("ed25519_base_2^20", "ctg"): _ed_base_ct(7),
+}
 # HBM bytes per launch measured with rocprofv3 PMC passes (tools/profile_all.sh -> tools/prof_summary.py;
 # summaries committed under profiles/): FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for
 # 16-byte-per-lane reads on gfx950, plus WRITE_SIZE, summed over the kernels of one step.  Counters
