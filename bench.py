@@ -140,8 +140,8 @@ WORKLOADS = {
     "bls12_381_g1_var_2^20": ("bls12_381_g1", "var", 1 << 20, 224, _var_unsat(14, 14, 32, 1, 570, 2 * 12 * 12)),
 }
 def _base_ct(n, nz, sb, nbits, w, merged_y3=False):
-    """Secret-scalar fixed base (kernels_ct.hpp k_scalarmul_base_ct): ceil((8 SB + 1) / w) signed windows, EVERY one a
-    mixed XYZZ addition (8 products + 2 squares; Y3 in one reduction where the field merges it), the top
+    """Secret-scalar fixed base (kernels_ct.hpp k_scalarmul_base_ct): ceil((8 SB + 1) / w) signed windows, every one but
+    the first a mixed XYZZ addition (8 products + 2 squares; Y3 in one reduction where the field merges it), the top
     ct_unsafe_windows() also 2 * entry from affine coordinates (4 products + 3 squares), 2 products to the Jacobian row,
     then the normalisation as in _var_unsat."""
     prod, sq, red = n * n, n * (n + 1) // 2, n * nz
@@ -151,7 +151,7 @@ def _base_ct(n, nz, sb, nbits, w, merged_y3=False):
 
     nwin = (8 * sb + 1 + w - 1) // w
     unsafe = nwin - (nbits + w - 1) // w + 1
-    return {"mad": nwin * cost(8, 2, 9 if merged_y3 else None) + unsafe * cost(4, 3) + cost(2, 0) + cost(9, 1), "pair": 0}
+    return {"mad": (nwin - 1) * cost(8, 2, 9 if merged_y3 else None) + unsafe * cost(4, 3) + cost(2, 0) + cost(9, 1), "pair": 0}
 
 
 def _ed_base_ct(w):

@@ -57,6 +57,12 @@ namespace eccx {
 #ifndef ECCX_CT_BASE_OCC9
 #define ECCX_CT_BASE_OCC9 4
 #endif
+#ifndef ECCX_CT_SCAN_SMEM
+#define ECCX_CT_SCAN_SMEM 0  // 1: the scan reads the slice through the scalar cache (ct_scan_smem) instead of an LDS copy
+#endif
+#ifndef ECCX_CT_SCAN_PK
+#define ECCX_CT_SCAN_PK 1  // the LDS scan keeps two words per instruction (ct_scan_lds_pk); 0: one v_cndmask_b32 per word
+#endif
 #ifndef ECCX_CT_GATHER_BITS
 #define ECCX_CT_GATHER_BITS 7
 #endif
@@ -116,6 +122,66 @@ ECCX_DEV void ct_scan_lds(uint32_t (&out)[EW], const uint4* __restrict__ slice, 
   }
 }
 
+// The same scan at two words per instruction.  A limb (< 2^30) with bit 30 set is the bit pattern of a positive, normal
+// binary32 number (exponent field 10xxxxxx), so e * 1.0 + (+0) = e, e * 0.0 + acc = acc EXACTLY, whatever the rounding
+// and denormal modes: v_pk_fma_f32 against the lane's (1.0, 1.0) / (0.0, 0.0) keeps or drops two words at once, at the
+// issue cost of one v_cndmask_b32.  No NaN, infinity or denormal can arise (every input is normal or +0, one factor
+// is 0 or 1), every lane executes every instruction, and the unit's latency does not depend on its operands.
+// The slice in LDS holds the words tagged (CtSliceStage::store<true>); the tag is masked off the selected entry.
+// Digit 0 leaves +0 everywhere: out = 0.
+constexpr uint32_t CT_F32_TAG = 0x40000000u;
+ECCX_DEV void ct_fsel2(uint64_t& acc, uint64_t e, uint64_t m) {  // both halves take the LOW word of m (op_sel_hi)
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(e), "v"(m));
+}
+template <int EW, int ENT, int USED, int B>
+ECCX_DEV void ct_scan_lds_pk(uint32_t (&out)[EW], const uint4* __restrict__ slice, uint32_t d) {
+  // limbs below 2^29, a top limb below 3 * 2^28: bits 29..23 are never all ones, so the tagged word is never infinity / NaN
+  static_assert(EW % 4 == 0 && USED <= EW && B <= 29, "entries are padded to 16 bytes; limbs leave bit 30 free");
+  constexpr int PAIRS = (USED + 1) / 2;
+  uint64_t acc[PAIRS];
+#pragma unroll
+  for (int p = 0; p < PAIRS; ++p) acc[p] = 0;  // (+0.0, +0.0)
+#pragma unroll 2
+  for (int j = 0; j < ENT; ++j) {
+    uint32_t m;  // 1.0f for the lane whose digit is j + 1, else 0.0f
+    asm("v_cndmask_b32_e64 %0, 0, 1.0, %1" : "=v"(m) : "s"(__builtin_amdgcn_uicmp(d, (uint32_t)(j + 1), 32 /* ICMP_EQ */)));
+    const uint64_t m2 = m;  // the upper word is not read
+    uint4 v[EW / 4];
+#pragma unroll
+    for (int c = 0; c < EW / 4; ++c) v[c] = slice[j * (EW / 4) + c];
+#pragma unroll
+    for (int p = 0; p < PAIRS; ++p) {
+      const uint4 q = v[p / 2];
+      ct_fsel2(acc[p], (p & 1) ? (((uint64_t)q.w << 32) | q.z) : (((uint64_t)q.y << 32) | q.x), m2);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < EW; ++k) out[k] = k < 2 * PAIRS ? ((uint32_t)(acc[k / 2] >> (32 * (k & 1))) & ~CT_F32_TAG) : 0u;
+}
+
+// select_from_table with the entries in SCALAR registers: the slice address is the same for every lane, so the
+// entry words arrive by s_load through the scalar cache and each costs one v_and_or_b32 against the lane's
+// all-ones / zero mask -- no copy of the slice in LDS, no barrier per window.  out must be zero on entry.
+template <int EW, int ENT>
+ECCX_DEV void ct_scan_smem(uint32_t (&out)[EW], const uint4* __restrict__ slice, uint32_t d) {
+  static_assert(EW % 4 == 0, "entries are padded to 16 bytes");
+#pragma unroll 2
+  for (int j = 0; j < ENT; ++j) {
+    uint32_t mask = 0;
+    ct_cmov1(mask, 0xffffffffu, __builtin_amdgcn_uicmp(d, (uint32_t)(j + 1), 32 /* ICMP_EQ */));
+    uint4 v[EW / 4];
+#pragma unroll
+    for (int c = 0; c < EW / 4; ++c) v[c] = slice[j * (EW / 4) + c];
+#pragma unroll
+    for (int c = 0; c < EW / 4; ++c) {
+      asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(out[4 * c]) : "s"(v[c].x), "v"(mask));
+      asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(out[4 * c + 1]) : "s"(v[c].y), "v"(mask));
+      asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(out[4 * c + 2]) : "s"(v[c].z), "v"(mask));
+      asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(out[4 * c + 3]) : "s"(v[c].w), "v"(mask));
+    }
+  }
+}
+
 // The workgroup's copy of one window slice, global -> registers (issued early) -> LDS (written late)
 template <int SLICE4>
 struct CtSliceStage {
@@ -128,11 +194,13 @@ struct CtSliceStage {
       r[i] = src[at < SLICE4 ? at : SLICE4 - 1];  // clamped: uniform trip count, no out-of-bounds read
     }
   }
+  template <bool TAGGED = false>  // TAGGED: every word | CT_F32_TAG, for ct_scan_lds_pk
   ECCX_DEV void store(uint4* __restrict__ dst) const {
+    constexpr uint32_t T = TAGGED ? CT_F32_TAG : 0u;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int at = i * WG + (int)threadIdx.x;
-      if (at < SLICE4) dst[at] = r[i];
+      if (at < SLICE4) dst[at] = make_uint4(r[i].x | T, r[i].y | T, r[i].z | T, r[i].w | T);
     }
   }
 };
@@ -219,8 +287,8 @@ __global__ void k_affine_to_cttable(size_t entries, const uint8_t* __restrict__ 
   Fe<L> px, py;
   fe_load_be<CS>(px, affine + i * (size_t)(2 * FB));
   fe_load_be<CS>(py, affine + i * (size_t)(2 * FB) + FB);
-  const auto ux = u_to_mont<CU>(px);
-  const auto uy = u_to_mont<CU>(py);
+  const auto ux = u_reduce(u_to_mont<CU>(px));  // exact digits: every limb < 2^B (the scan tags bit 30)
+  const auto uy = u_reduce(u_to_mont<CU>(py));
   uint32_t* o = table + i * (size_t)EW;
 #pragma unroll
   for (int k = 0; k < EW; ++k) o[k] = k < CU::N ? ux.v[k] : (k < 2 * CU::N ? uy.v[k - CU::N] : 0u);
@@ -246,7 +314,8 @@ __global__ void __launch_bounds__(WG, ct_base_occupancy<CU>()) k_scalarmul_base_
   constexpr int UNSAFE = ct_unsafe_windows<CU, GATHER>();
   static_assert(UNSAFE >= 1 && UNSAFE <= NWIN, "window bookkeeping");
   using T = U<CU, 1, 3>;
-  __shared__ uint4 lds[GATHER ? 1 : 2][GATHER ? 1 : SLICE4];
+  constexpr bool STAGED = !GATHER && !ECCX_CT_SCAN_SMEM;  // the slice goes through LDS
+  __shared__ uint4 lds[STAGED ? 2 : 1][STAGED ? SLICE4 : 1];
   const uint4* __restrict__ gtab = reinterpret_cast<const uint4*>(table);
   T one;
 #pragma unroll
@@ -257,10 +326,10 @@ __global__ void __launch_bounds__(WG, ct_base_occupancy<CU>()) k_scalarmul_base_
     const size_t idx = active ? gid : n - 1;
     const uint8_t* __restrict__ k = scalars + idx * (size_t)SB;
     CtSliceStage<SLICE4> stage;
-    if constexpr (!GATHER) {
+    if constexpr (STAGED) {
       stage.load(gtab);
       __syncthreads();  // the previous batch's last reads of buffer 0 are done
-      stage.store(lds[0]);
+      stage.template store<(ECCX_CT_SCAN_PK != 0)>(lds[0]);
       __syncthreads();
     }
     UXyzz<CU> q;
@@ -269,7 +338,7 @@ __global__ void __launch_bounds__(WG, ct_base_occupancy<CU>()) k_scalarmul_base_
     u_set_zero(q.zz);
     u_set_zero(q.zzz);
     for (int w = 0; w < NWIN; ++w) {
-      if constexpr (!GATHER) {
+      if constexpr (STAGED) {
         if (w + 1 < NWIN) stage.load(gtab + (size_t)(w + 1) * SLICE4);
       }
       uint32_t d;
@@ -281,7 +350,9 @@ __global__ void __launch_bounds__(WG, ct_base_occupancy<CU>()) k_scalarmul_base_
       } else {
 #pragma unroll
         for (int i = 0; i < EW; ++i) ew[i] = 0;
-        ct_scan_lds<EW, ENT>(ew, lds[w & 1], d);
+        if constexpr (STAGED && ECCX_CT_SCAN_PK) ct_scan_lds_pk<EW, ENT, 2 * N, CU::B>(ew, lds[w & 1], d);
+        else if constexpr (STAGED) ct_scan_lds<EW, ENT>(ew, lds[w & 1], d);
+        else ct_scan_smem<EW, ENT>(ew, gtab + (size_t)w * SLICE4, d);
       }
       T x2, y2;
 #pragma unroll
@@ -294,7 +365,9 @@ __global__ void __launch_bounds__(WG, ct_base_occupancy<CU>()) k_scalarmul_base_
       const bool q_inf = u_limbs_all_zero(q.zz);
       const bool skip = d == 0;
       UXyzz<CU> sum;
-      if (w >= NWIN - UNSAFE) {  // loop counter: the same for every lane and every scalar
+      if (w == 0) {
+        sum = q;  // nothing to add to yet: the accumulator is at infinity and the patch below makes the sum the entry
+      } else if (w >= NWIN - UNSAFE) {  // loop counter: the same for every lane and every scalar
         bool hz, rz;
         uxyzz_madd<CU, true>(sum, hz, rz, q, x2, y2);
         UXyzz<CU> dbl;
@@ -325,8 +398,8 @@ __global__ void __launch_bounds__(WG, ct_base_occupancy<CU>()) k_scalarmul_base_
       u_cmov_ct(q.y, mk, sum.y);
       u_cmov_ct(q.zz, mk, sum.zz);
       u_cmov_ct(q.zzz, mk, sum.zzz);
-      if constexpr (!GATHER) {
-        if (w + 1 < NWIN) stage.store(lds[(w + 1) & 1]);
+      if constexpr (STAGED) {
+        if (w + 1 < NWIN) stage.template store<(ECCX_CT_SCAN_PK != 0)>(lds[(w + 1) & 1]);
         __syncthreads();
       }
     }
@@ -352,7 +425,8 @@ __global__ void __launch_bounds__(WG, 4) k_ed_scalarmul_base_ct(size_t n, const 
   constexpr int EW = ct_entry_words<CU>();
   constexpr int SLICE4 = ENT * EW / 4;
   using T = U<CU, 1, 3>;
-  __shared__ uint4 lds[GATHER ? 1 : 2][GATHER ? 1 : SLICE4];
+  constexpr bool STAGED = !GATHER && !ECCX_CT_SCAN_SMEM;
+  __shared__ uint4 lds[STAGED ? 2 : 1][STAGED ? SLICE4 : 1];
   const uint4* __restrict__ gtab = reinterpret_cast<const uint4*>(table);
   for (size_t base = (size_t)blockIdx.x * WG; base < n; base += (size_t)gridDim.x * WG) {
     const size_t gid = base + threadIdx.x;
@@ -360,17 +434,17 @@ __global__ void __launch_bounds__(WG, 4) k_ed_scalarmul_base_ct(size_t n, const 
     const size_t idx = active ? gid : n - 1;
     const uint8_t* __restrict__ k = scalars + idx * 32;
     CtSliceStage<SLICE4> stage;
-    if constexpr (!GATHER) {
+    if constexpr (STAGED) {
       stage.load(gtab);
       __syncthreads();
-      stage.store(lds[0]);
+      stage.template store<(ECCX_CT_SCAN_PK != 0)>(lds[0]);
       __syncthreads();
     }
     T qx, qy, qz, qt;  // the neutral element (0, 1, 1, 0)
     u_set_zero(qx); u_set_zero(qy); u_set_zero(qz); u_set_zero(qt);
     qy.v[0] = 1; qz.v[0] = 1;
     for (int w = 0; w < NWIN; ++w) {
-      if constexpr (!GATHER) {
+      if constexpr (STAGED) {
         if (w + 1 < NWIN) stage.load(gtab + (size_t)(w + 1) * SLICE4);
       }
       uint32_t d;
@@ -386,9 +460,17 @@ __global__ void __launch_bounds__(WG, 4) k_ed_scalarmul_base_ct(size_t n, const 
       } else {
 #pragma unroll
         for (int i = 0; i < EW; ++i) ew[i] = 0;
-        ew[0] = 1;  // y - x
-        ew[N] = 1;  // y + x
-        ct_scan_lds<EW, ENT>(ew, lds[w & 1], d);
+        if constexpr (STAGED && !ECCX_CT_SCAN_PK) {
+          ew[0] = 1;  // y - x
+          ew[N] = 1;  // y + x
+          ct_scan_lds<EW, ENT>(ew, lds[w & 1], d);
+        } else {
+          if constexpr (STAGED) ct_scan_lds_pk<EW, ENT, 3 * N, CU::B>(ew, lds[w & 1], d);
+          else ct_scan_smem<EW, ENT>(ew, gtab + (size_t)w * SLICE4, d);
+          const uint64_t mz = ct_mask(d == 0);
+          ct_cmov1(ew[0], 1u, mz);
+          ct_cmov1(ew[N], 1u, mz);
+        }
       }
       T a, b, t2d, ym, yp;
 #pragma unroll
@@ -398,8 +480,8 @@ __global__ void __launch_bounds__(WG, 4) k_ed_scalarmul_base_ct(size_t n, const 
       U<CU, 2, 4> t2;
       u_select_ct(t2, neg, u_neg(t2d), u_as<2, 4>(t2d));
       ued_add_niels<CU, 2, 4>(qx, qy, qz, qt, ym, yp, t2);
-      if constexpr (!GATHER) {
-        if (w + 1 < NWIN) stage.store(lds[(w + 1) & 1]);
+      if constexpr (STAGED) {
+        if (w + 1 < NWIN) stage.template store<(ECCX_CT_SCAN_PK != 0)>(lds[(w + 1) & 1]);
         __syncthreads();
       }
     }

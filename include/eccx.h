@@ -52,7 +52,9 @@
  * STRUCTURE, checked on the compiled code (tools/isa_histogram.py --branches, profiles/r03_isa_ct_*.txt):
  *   - no memory address depends on a scalar digit: every lookup reads every entry of its table (fixed base:
  *     the window's slice, staged in LDS by the workgroup; variable base: all rows of the lane's own table)
- *     and keeps one with v_cndmask; the scalar bytes are read at addresses that depend on the window number;
+ *     and keeps one with a per-lane select executed by every lane for every entry (v_cndmask_b32, or for the
+ *     fixed-base slices v_pk_fma_f32 against 1.0 / 0.0 on words that are exact under it: kernels_ct.hpp
+ *     ct_scan_lds_pk); the scalar bytes are read at addresses that depend on the window number;
  *   - no branch depends on scalar-derived data: signs, digit 0, accumulator at infinity and accumulator ==
  *     +-entry are resolved by selects (written as inline assembly: the compiler otherwise turns ?: into EXEC-
  *     masked regions it can skip); the conditional branches left are loop counters and batch bounds;

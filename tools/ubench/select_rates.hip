@@ -12,7 +12,8 @@
 
 constexpr int GROUPS = 8;
 enum Pat { SMOV_CND4, VCMP_CND4, VCMP_CND8, CND4_E64, BFI4, VCMP_CND1, BPERM_ID, BPERM_RANDOM, BPERM_SAME, BPERM_FOLD,
-           EXEC_MOV32_DIGIT, EXEC_MOV32_FULL, EXEC_MOV32_LOWER, EXEC_MOV32_ZERO, EXEC_MOV64_DIGIT, EXEC_MOV64_FULL, EXEC_MOV64_LOWER, EXEC_MOV64_ZERO };
+           EXEC_MOV32_DIGIT, EXEC_MOV32_FULL, EXEC_MOV32_LOWER, EXEC_MOV32_ZERO, EXEC_MOV64_DIGIT, EXEC_MOV64_FULL, EXEC_MOV64_LOWER, EXEC_MOV64_ZERO,
+           PK_FMA_F32, FMA_F64, AND_OR4 };
 
 template <int P>
 __global__ void __launch_bounds__(256) k_sel(uint32_t* out, uint64_t* clocks, int iters, uint32_t seed) {
@@ -26,6 +27,14 @@ __global__ void __launch_bounds__(256) k_sel(uint32_t* out, uint64_t* clocks, in
       a[g][i] = (lane ^ seed) + g * 31u + i * 7u;
     }
   const uint32_t d = (lane * 7u + seed) & 31u;  // the lane's "digit"
+  uint64_t o64[GROUPS][2], a64[GROUPS][2];  // the floating-point forms: words tagged once, outside the timed loop; accumulators start at +0
+#pragma unroll
+  for (int g = 0; g < GROUPS; ++g)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      o64[g][h] = 0;
+      a64[g][h] = ((uint64_t)((a[g][2 * h + 1] & 0x3fffffffu) | 0x40000000u) << 32) | ((a[g][2 * h] & 0x3fffffffu) | 0x40000000u);
+    }
   const uint64_t t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   for (int it = 0; it < iters; ++it) {
     const uint32_t j = (uint32_t)it & 31u;  // wave-uniform "entry index"
@@ -62,6 +71,27 @@ __global__ void __launch_bounds__(256) k_sel(uint32_t* out, uint64_t* clocks, in
                      : "v"(a[g][0]), "v"(a[g][1]), "v"(a[g][2]), "v"(a[g][3]), "v"(m));
       } else if constexpr (P == VCMP_CND1) {  // a quarter of an op
         asm volatile("v_cmp_eq_u32_e32 vcc, %3, %2\n\tv_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(o[g][0]) : "v"(a[g][0]), "v"(d), "s"(j) : "vcc");
+      } else if constexpr (P == PK_FMA_F32 || P == FMA_F64) {
+        // the select as an exact floating-point multiply-add: words tagged with bit 30 are normal binary32 numbers (pairs
+        // of them, tagged in the upper word, normal binary64 numbers), e * 1.0 + 0 = e and e * 0.0 + acc = acc exactly:
+        // two words per instruction (kernels_ct.hpp ct_scan_lds_pk)
+        uint64_t &o0 = o64[g][0], &o1 = o64[g][1];
+        const uint64_t a0 = a64[g][0], a1 = a64[g][1];
+        if constexpr (P == PK_FMA_F32) {
+          const uint32_t m = (d == j) ? 0x3f800000u : 0u;
+          const uint64_t m2 = ((uint64_t)m << 32) | m;
+          // acc = a * m + acc * (1 - m) would need two instructions; the scan's form is acc = a * m + acc with acc = 0
+          // until the one entry whose m is 1: same instruction, same operands' classes
+          asm volatile("v_pk_fma_f32 %0, %2, %4, %0\n\tv_pk_fma_f32 %1, %3, %4, %1" : "+v"(o0), "+v"(o1) : "v"(a0), "v"(a1), "v"(m2));
+        } else {
+          const uint64_t m2 = (d == j) ? 0x3ff0000000000000ull : 0ull;
+          asm volatile("v_fma_f64 %0, %2, %4, %0\n\tv_fma_f64 %1, %3, %4, %1" : "+v"(o0), "+v"(o1) : "v"(a0), "v"(a1), "v"(m2));
+        }
+      } else if constexpr (P == AND_OR4) {
+        const uint32_t m = 0u - (uint32_t)(d == j);
+        asm volatile("v_and_or_b32 %0, %4, %8, %0\n\tv_and_or_b32 %1, %5, %8, %1\n\tv_and_or_b32 %2, %6, %8, %2\n\tv_and_or_b32 %3, %7, %8, %3"
+                     : "+v"(o[g][0]), "+v"(o[g][1]), "+v"(o[g][2]), "+v"(o[g][3])
+                     : "v"(a[g][0]), "v"(a[g][1]), "v"(a[g][2]), "v"(a[g][3]), "v"(m));
       } else if constexpr (P >= EXEC_MOV32_DIGIT) {
         // the select as an EXEC-masked move: exec = lane mask, v_mov, exec = all.  A VALU instruction issues whatever EXEC
         // holds -- if the hardware skipped a half-wave whose lanes are all masked off, the time would depend on the
@@ -104,6 +134,8 @@ __global__ void __launch_bounds__(256) k_sel(uint32_t* out, uint64_t* clocks, in
   for (int g = 0; g < GROUPS; ++g)
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc ^= o[g][i];
+#pragma unroll
+  for (int g = 0; g < GROUPS; ++g) acc ^= (uint32_t)(o64[g][0] ^ (o64[g][0] >> 32) ^ o64[g][1] ^ (o64[g][1] >> 32));
   if (acc == 0x12345678u) out[lane] = acc;
   if (threadIdx.x == 0 && blockIdx.x == 0) { clocks[0] = t1 - t0; clocks[1] = r1 - r0; }
 }
@@ -158,6 +190,9 @@ int main() {
     run<EXEC_MOV64_FULL>("exec = all lanes, 2 v_mov_b64", 1, dout, dclk, blocks, iters);
     run<EXEC_MOV64_LOWER>("exec = lower half only, 2 v_mov_b64", 1, dout, dclk, blocks, iters);
     run<EXEC_MOV64_ZERO>("exec = no lane, 2 v_mov_b64", 1, dout, dclk, blocks, iters);
+    run<PK_FMA_F32>("2 v_pk_fma_f32 against (1.0, 1.0) / (0.0, 0.0)", 1, dout, dclk, blocks, iters);
+    run<FMA_F64>("2 v_fma_f64 against 1.0 / 0.0", 1, dout, dclk, blocks, iters);
+    run<AND_OR4>("4 v_and_or_b32, VGPR mask", 1, dout, dclk, blocks, iters);
     run<BPERM_ID>("4 ds_bpermute_b32, identity", 1, dout, dclk, blocks, iters / 4);
     run<BPERM_RANDOM>("4 ds_bpermute_b32, random source in 0..31", 1, dout, dclk, blocks, iters / 4);
     run<BPERM_SAME>("4 ds_bpermute_b32, every lane the same source", 1, dout, dclk, blocks, iters / 4);
