@@ -99,3 +99,34 @@ def test_every_reachable_digit_has_a_table_scalar(sb, w):
                 assert i == nwin - 1 and d == 1 << shift
                 seen_special = True
     assert seen_special
+
+
+def test_tagged_limbs_survive_the_floating_point_select():
+    """kernels_ct.hpp ct_scan_lds_pk selects table words with v_pk_fma_f32: acc = e * m + acc, m = 1.0 for the lane's
+    digit and 0.0 otherwise, on limbs tagged with bit 30.  What the kernel relies on, checked here in IEEE binary32
+    (numpy): a tagged limb is a positive normal number; e * 1 + 0 and e * 0 + acc reproduce bit patterns exactly; the
+    accumulator of a digit that matches no entry stays +0.  Limbs: every value below 2^29 that matters at the edges,
+    top limbs up to 3 * 2^28 - 1 (P-521's, the largest), and random ones."""
+    import numpy as np
+
+    TAG = np.uint32(0x40000000)
+    rng = np.random.default_rng(5)
+    limbs = np.concatenate([
+        np.array([0, 1, 2, (1 << 23) - 1, 1 << 23, (1 << 28) - 1, 1 << 28, (1 << 29) - 1, 1 << 29, 3 * (1 << 28) - 1], dtype=np.uint32),
+        rng.integers(0, 3 << 28, size=200000, dtype=np.uint32)])
+    tagged = limbs | TAG
+    f = tagged.view(np.float32)
+    assert np.all(np.isfinite(f)) and np.all(f >= np.float32(2.0))         # normal, positive: exponent field 10xxxxxx / 110xxxxx
+    expo = (tagged >> np.uint32(23)) & np.uint32(0xFF)
+    assert expo.min() >= 128 and expo.max() < 255
+    one, zero = np.float32(1.0), np.float32(0.0)
+    with np.errstate(all="raise"):                                          # no overflow, underflow or invalid operation
+        kept = f * one + zero                                               # the lane's entry arrives on a +0 accumulator
+        assert np.array_equal(kept.view(np.uint32), tagged)
+        other = np.roll(f, 1)
+        after = other * zero + kept                                         # the entries after it leave it alone
+        assert np.array_equal(after.view(np.uint32), tagged)
+        nothing = f * zero + zero                                           # digit 0: nothing selected
+        assert np.all(nothing.view(np.uint32) == 0)
+    assert np.array_equal(after.view(np.uint32) & ~TAG, limbs)              # the tag comes off
+    assert np.all((nothing.view(np.uint32) & ~TAG) == 0)
