@@ -155,9 +155,9 @@ def _base_ct(n, nz, sb, nbits, w, merged_y3=False):
 
 
 def _ed_base_ct(w):
-    """edwards25519 fixed base, secret scalars: ceil(257 / w) complete additions of 7 products (81 + 9 mads), the
-    normalisation (5 products)"""
-    return {"mad": (((257 + w - 1) // w) * 7 + 5) * 90, "pair": 0}
+    """edwards25519 fixed base, secret scalars: ceil(257 / w) windows, the first loaded (1 product), the others complete
+    additions of 7 products (81 + 9 mads), the normalisation (5 products)"""
+    return {"mad": ((((257 + w - 1) // w) - 1) * 7 + 1 + 5) * 90, "pair": 0}
 
 
 # multiplier instructions of the non-default variants that have a count of their own.  Window widths as compiled:

@@ -479,7 +479,19 @@ __global__ void __launch_bounds__(WG, 4) k_ed_scalarmul_base_ct(size_t n, const 
       u_select_ct(yp, neg, a, b);
       U<CU, 2, 4> t2;
       u_select_ct(t2, neg, u_neg(t2d), u_as<2, 4>(t2d));
-      ued_add_niels<CU, 2, 4>(qx, qy, qz, qt, ym, yp, t2);
+      if (w == 0) {
+        // the accumulator is the neutral element: (x, y) given as (ym, yp) = (y - x, y + x) is
+        // (2(yp - ym) : 2(yp + ym) : 4 : (yp - ym)(yp + ym)) -- one product instead of seven; digit 0 (1, 1, 0) gives (0 : 4 : 4 : 0)
+        const auto dx = u_reduce(u_sub(yp, ym));
+        const auto sy = u_reduce(u_add(yp, ym));
+        qx = u_reduce(u_add(dx, dx));
+        qy = u_reduce(u_add(sy, sy));
+        u_set_zero(qz);
+        qz.v[0] = 4;
+        qt = u_fit<1, 3>(u_mul(dx, sy));
+      } else {
+        ued_add_niels<CU, 2, 4>(qx, qy, qz, qt, ym, yp, t2);
+      }
       if constexpr (STAGED) {
         if (w + 1 < NWIN) stage.template store<(ECCX_CT_SCAN_PK != 0)>(lds[(w + 1) & 1]);
         __syncthreads();
