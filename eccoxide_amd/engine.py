@@ -64,7 +64,13 @@ def _proj_width(cid: int) -> int:
 class Engine:
     """One engine context bound to one GPU (eccx_init / eccx_shutdown)."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, secret_scalars: bool = False):
+        """secret_scalars: what `ct_scan=None` means in the scalar-multiplication calls of this engine -- True selects the
+        secret-scalar kernels (ECCX_CT_SCAN: every table entry read at every lookup, no branch on scalar-derived data;
+        include/eccx.h "SIDE CHANNELS") for key generation, signing and ECDH; False (verification, public keys, tests) the
+        faster public-scalar kernels, whose lookups and branches follow the digits.  The C++ and Rust wrappers take the
+        same choice with no default (eccx::Secrecy, eccoxide_gpu::Secrecy)."""
+        self.secret_scalars = bool(secret_scalars)
         self._lib = _lib.load()
         self._ctx = ctypes.c_void_p()
         rc = self._lib.eccx_init(int(device), ctypes.byref(self._ctx))
@@ -88,6 +94,9 @@ class Engine:
 
     def __exit__(self, *exc):
         self.close()
+
+    def _secret(self, ct_scan: Optional[bool]) -> bool:
+        return self.secret_scalars if ct_scan is None else bool(ct_scan)
 
     def _check(self, rc: int):
         if rc != 0:
@@ -136,11 +145,11 @@ class Engine:
 
     # ---- host buffers ------------------------------------------------------
     def scalarmul_var(self, curve, scalars: bytes, points: bytes, *, validate: bool = False,
-                      want_proj: bool = False, mirror: bool = False, ct_scan: bool = False,
+                      want_proj: bool = False, mirror: bool = False, ct_scan: Optional[bool] = None,
                       assume_subgroup: bool = False):
         """out[i] = scalars[i] * points[i]; returns (affine bytes, flags[, proj bytes]).
-        mirror=True (implied by want_proj) runs the reference-mirroring kernels; ct_scan=True those
-        with the full-table scan (secret scalars); assume_subgroup=True (bls12_381_g1) the
+        mirror=True (implied by want_proj) runs the reference-mirroring kernels; ct_scan=True the secret-scalar
+        ladder (every table row read at every lookup, selects only; None: the engine's secret_scalars); assume_subgroup=True (bls12_381_g1) the
         endomorphism ladder for bases known to be in G1."""
         cid = curve_id(curve)
         sb, fb = scalar_bytes(cid), field_bytes(cid)
@@ -154,16 +163,17 @@ class Engine:
         proj = ctypes.create_string_buffer(max(1, n * _proj_width(cid))) if want_proj else None
         rc = self._lib.eccx_scalarmul_var(self._ctx, cid, n, scalars, points, out, flags, proj,
                                           (VALIDATE_POINTS if validate else 0) | (MIRROR_REFERENCE if mirror else 0)
-                                          | (CT_SCAN if ct_scan else 0) | (ASSUME_SUBGROUP if assume_subgroup else 0))
+                                          | (CT_SCAN if self._secret(ct_scan) else 0) | (ASSUME_SUBGROUP if assume_subgroup else 0))
         self._check(rc)
         res = (out.raw[: n * 2 * fb], flags.raw[:n])
         return res + (proj.raw[: n * _proj_width(cid)],) if want_proj else res
 
     def scalarmul_base(self, curve, scalars: bytes, *, want_proj: bool = False, mirror: bool = False,
-                       ct_scan: bool = False, ct_gather: bool = False):
+                       ct_scan: Optional[bool] = None, ct_gather: bool = False):
         """out[i] = scalars[i] * G via the fixed-base comb table.
-        mirror=True (implied by want_proj) runs the reference-mirroring kernels; ct_scan=True the
-        reference's 4-bit comb with the full-table scan (secret scalars)."""
+        mirror=True (implied by want_proj) runs the reference-mirroring kernels; ct_scan=True the secret-scalar comb
+        (signed windows, every entry of a window read by every lane; None: the engine's secret_scalars); ct_gather=True its
+        cross-lane lookup (ECCX_CT_GATHER, opt-in)."""
         cid = curve_id(curve)
         sb, fb = scalar_bytes(cid), field_bytes(cid)
         if len(scalars) % sb:
@@ -173,7 +183,7 @@ class Engine:
         flags = ctypes.create_string_buffer(max(1, n))
         proj = ctypes.create_string_buffer(max(1, n * _proj_width(cid))) if want_proj else None
         rc = self._lib.eccx_scalarmul_base(self._ctx, cid, n, scalars, out, flags, proj,
-                                           (MIRROR_REFERENCE if mirror else 0) | (CT_SCAN if ct_scan or ct_gather else 0)
+                                           (MIRROR_REFERENCE if mirror else 0) | (CT_SCAN if self._secret(ct_scan) or ct_gather else 0)
                                            | (CT_GATHER if ct_gather else 0))
         self._check(rc)
         res = (out.raw[: n * 2 * fb], flags.raw[:n])
@@ -375,7 +385,7 @@ class Engine:
 
     # ---- device tensors (torch.uint8, resident on this engine's GPU) -----------
     def scalarmul_var_t(self, curve, scalars, points, out=None, flags=None, proj=None, *,
-                        validate: bool = False, mirror: bool = False, ct_scan: bool = False,
+                        validate: bool = False, mirror: bool = False, ct_scan: Optional[bool] = None,
                         assume_subgroup: bool = False, stream: Optional[int] = None):
         """Device-resident variant: tensors are torch.uint8 CUDA tensors; the launch is
         enqueued on `stream` (raw hipStream_t handle; default: torch's current stream)."""
@@ -398,13 +408,13 @@ class Engine:
                                               out.data_ptr(), flags.data_ptr(),
                                               proj.data_ptr() if proj is not None else None,
                                               (VALIDATE_POINTS if validate else 0) | (MIRROR_REFERENCE if mirror else 0)
-                                              | (CT_SCAN if ct_scan else 0) | (ASSUME_SUBGROUP if assume_subgroup else 0),
+                                              | (CT_SCAN if self._secret(ct_scan) else 0) | (ASSUME_SUBGROUP if assume_subgroup else 0),
                                               stream)
         self._check(rc)
         return out, flags
 
     def scalarmul_base_t(self, curve, scalars, out=None, flags=None, proj=None, *, stream: Optional[int] = None,
-                         table_in_lds: Optional[bool] = None, mirror: bool = False, ct_scan: bool = False,
+                         table_in_lds: Optional[bool] = None, mirror: bool = False, ct_scan: Optional[bool] = None,
                          ct_gather: bool = False):
         import torch
 
@@ -422,7 +432,7 @@ class Engine:
         rc = self._lib.eccx_scalarmul_base_dev(self._ctx, cid, n, scalars.data_ptr(), out.data_ptr(),
                                                flags.data_ptr(), proj.data_ptr() if proj is not None else None,
                                                (0 if table_in_lds is None else (TABLE_IN_LDS if table_in_lds else TABLE_IN_L2))
-                                               | (MIRROR_REFERENCE if mirror else 0) | (CT_SCAN if ct_scan or ct_gather else 0)
+                                               | (MIRROR_REFERENCE if mirror else 0) | (CT_SCAN if self._secret(ct_scan) or ct_gather else 0)
                                                | (CT_GATHER if ct_gather else 0),
                                                stream)
         self._check(rc)

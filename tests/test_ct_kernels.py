@@ -260,6 +260,25 @@ def test_ct_option_combinations(engine):
     assert a == b
 
 
+def test_engine_level_secrecy_selects_the_secret_scalar_kernels(oracle):
+    """Engine(device, secret_scalars=True): calls that do not say ct_scan= take the secret-scalar kernels -- visible from
+    outside through an option those kernels refuse (ECCX_ASSUME_SUBGROUP) -- and an explicit ct_scan=False still wins."""
+    import eccoxide_amd as E
+
+    with E.Engine(0, secret_scalars=True) as eng:
+        k = W.random_scalars("bls12_381_g1", 70, seed=9).tobytes()
+        pts = _bases(oracle, "bls12_381_g1", 70, 10)
+        want = oracle.var("bls12_381_g1", k, pts, threads=8)
+        assert eng.scalarmul_var("bls12_381_g1", k, pts) == (want[0], want[1])
+        with pytest.raises(E.EccxError) as ei:
+            eng.scalarmul_var("bls12_381_g1", k, pts, assume_subgroup=True)
+        assert "ASSUME_SUBGROUP" in str(ei.value)
+        assert eng.scalarmul_var("bls12_381_g1", k, pts, assume_subgroup=True, ct_scan=False) == (want[0], want[1])
+        kb = W.random_scalars("ed25519", 70, seed=11).tobytes()
+        wb = oracle.base("ed25519", kb, threads=8)
+        assert eng.scalarmul_base("ed25519", kb) == (wb[0], wb[1])
+
+
 @pytest.mark.parametrize("curve,log2n", [("p256r1", 20), ("ed25519", 20), ("p384r1", 19), ("p521r1", 19), ("bls12_381_g1", 20)])
 def test_ct_full_size_batches_match_the_default_kernels(engine, oracle, curve, log2n):
     """BASELINE.json's per-GPU batch sizes: the secret-scalar kernels against the default kernels on every unit,
