@@ -62,11 +62,16 @@
  * What still depends on data under ECCX_CT_SCAN: the BASE POINT -- rejected inputs (ECCX_VALIDATE_POINTS), a base
  * of order <= 8 (bls12_381_g1 cofactor points; never on a prime-order curve) or bytes that are no curve point
  * mark the unit, from the point alone, and it is redone by the reference-mirroring scan kernel; which units those
- * are is visible in timing.  edwards25519 VARIABLE base under ECCX_CT_SCAN is the reference's bit-serial
- * double-and-add with masked additions (no table).  ECCX_CT_GATHER (opt-in, fixed base) replaces the scan by a
- * cross-lane register gather; see the option.  No timing measurement backs a constant-time claim beyond the
- * microbenchmarks named there: GPU schedulers, caches and DVFS are not modelled.  eccx_x25519 is uniform by
- * construction (conditional swaps are selects, no table).
+ * are is visible in timing.  ECCX_CT_GATHER (opt-in, fixed base) replaces the scan by a cross-lane register
+ * gather; see the option.  eccx_x25519 is uniform by construction (conditional swaps are selects, no table).
+ * What was MEASURED (tools/ct_trace_check.py, profiles/r03_ct_instruction_counts.json): six scalar sets -- random,
+ * all zero, all ones, n - 1, one scalar repeated, random again -- execute exactly the same number of vector, scalar,
+ * memory and LDS instructions in every secret-scalar kernel and the same busy cycles to 1-3 %.  Their DURATIONS are
+ * not equal: a batch whose lanes all hold the same scalar runs 6-15 % shorter than a batch of random scalars,
+ * because the chip's power management holds a higher clock when the lanes compute on equal data (2.38-2.40 GHz
+ * against 2.25-2.29 for the p256r1 comb) -- the frequency side channel every DVFS processor has, the reference's
+ * CPUs included; two batches of independent random scalars are indistinguishable at the precision of that
+ * measurement.  GPU schedulers and caches are not modelled beyond these measurements.
  *
  * MEMORY AND BLOCKING.  A context is bound to one GPU and owns
  *   - the window-table slab of the variable-base ladders: resident lanes x 17 rows (P-256:

@@ -2,8 +2,8 @@
 """Dynamic check of the secret-scalar kernels: does the executed instruction stream depend on the scalars?
 
 The static side is the branch census (tools/isa_histogram.py --branches).  This is the dynamic side: the same batch
-of base points is multiplied by five very different scalar sets -- random, all zero, all ones (0xff..), order - 1,
-one random scalar repeated -- and the hardware's per-dispatch instruction counters (rocprofv3 PMC: vector, scalar,
+of base points is multiplied by six scalar sets -- random, all zero, all ones (0xff..), order - 1,
+one random scalar repeated, random again with another seed; after one warm-up pass the six run forward and then backward -- and the hardware's per-dispatch instruction counters (rocprofv3 PMC: vector, scalar,
 vector-memory read / write, LDS and scalar-memory instructions, waves) are compared kernel by kernel.  A kernel whose
 control flow and memory instruction stream do not depend on the scalars executes EXACTLY the same number of each,
 whatever the scalars; the public-scalar kernels run beside them as a control (they skip work on wave-uniform
@@ -23,7 +23,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 N = 1 << 16
-PATTERNS = ["random", "zero", "ones", "order_minus_1", "one_scalar_repeated"]
+PATTERNS = ["random", "zero", "ones", "order_minus_1", "one_scalar_repeated", "random_other_seed"]
+SEQUENCE = PATTERNS + PATTERNS[::-1]  # forward, then backward: a drift of the clock over the run cancels in a pattern's two durations
 CURVES = ["p256r1", "p384r1", "p521r1", "bls12_381_g1", "ed25519"]
 COUNTERS = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_INSTS_SMEM"]
 # what is launched per (curve, pattern), in this order; `kernels`: name fragments of the dispatches that belong to the call
@@ -44,6 +45,8 @@ def scalars(curve, pattern, n):
     sb = {"p256r1": 32, "p384r1": 48, "p521r1": 66, "bls12_381_g1": 32, "ed25519": 32}[curve]
     if pattern == "random":
         return W.random_scalars(curve, n, seed=77)
+    if pattern == "random_other_seed":
+        return W.random_scalars(curve, n, seed=79)
     if pattern == "zero":
         return np.zeros((n, sb), dtype=np.uint8)
     if pattern == "ones":
@@ -66,7 +69,7 @@ def run():
             eng.reserve(curve, N, var=True, ct=True)
             pts, _ = eng.scalarmul_base_t(curve, torch.from_numpy(W.random_scalars(curve, N, seed=76)).to(dev))
             torch.cuda.synchronize()
-            for pattern in PATTERNS:
+            for pattern in PATTERNS + SEQUENCE:  # one untimed pass first: the clock settles before the dispatches that are compared
                 ks = torch.from_numpy(scalars(curve, pattern, N)).to(dev)
                 for label, kw, _ in CALLS:
                     kw = dict(kw)
@@ -81,10 +84,10 @@ def run():
 def summarize(root):
     dbs = glob.glob(os.path.join(root, "**", "*.db"), recursive=True)
     db = sqlite3.connect(dbs[0])
-    rows = db.execute("select dispatch_id, kernel_name, grid_size, counter_name, value from counters_collection").fetchall()
+    rows = db.execute("select dispatch_id, kernel_name, grid_size, counter_name, value, duration from counters_collection").fetchall()
     disp = {}
-    for d, name, grid, counter, value in rows:
-        rec = disp.setdefault(d, {"kernel": name.replace("void ", "").split("(")[0], "grid": grid, "c": {}})
+    for d, name, grid, counter, value, duration in rows:
+        rec = disp.setdefault(d, {"kernel": name.replace("void ", "").split("(")[0], "grid": grid, "c": {}, "us": duration / 1e3})
         rec["c"][counter] = rec["c"].get(counter, 0.0) + value
     order = [disp[d] for d in sorted(disp)]
     # replay the launch order of run(): per curve, after the setup dispatches, PATTERNS x CALLS; dispatches are matched
@@ -108,18 +111,32 @@ def summarize(root):
                     continue
                 if "scalarmul_base_ct<" in k and (k.endswith(", true>") != gather):
                     continue
-                per_kernel.setdefault(k, []).append(r["c"])
+                per_kernel.setdefault(k, []).append(dict(r["c"], duration_us=r["us"]))
             entry = {}
             for k, runs in per_kernel.items():
                 # the timed region launches each kernel once per pattern (the first len(PATTERNS) dispatches after setup)
-                runs = runs[-len(PATTERNS):]
+                runs = runs[-len(SEQUENCE):]
                 same = all(all(run.get(c) == runs[0].get(c) for c in COUNTERS) for run in runs)
+                us = [(runs[i]["duration_us"] + runs[len(SEQUENCE) - 1 - i]["duration_us"]) / 2 for i in range(len(PATTERNS))]
+                # GRBM_GUI_ACTIVE counts cycles on each of the 8 XCDs: busy cycles of the dispatch = sum / 8
+                cyc = [(runs[i].get("GRBM_GUI_ACTIVE", 0) + runs[len(SEQUENCE) - 1 - i].get("GRBM_GUI_ACTIVE", 0)) / 16 for i in range(len(PATTERNS))]
+                # two dispatches per pattern (run forward, then backward), counters attached: durations are indicative only
+                # (they include the clock the chip chose for that dispatch), the instruction counts are the evidence
                 entry[k] = {"identical_across_scalar_patterns": same,
-                            "per_pattern": {p: {c: run.get(c) for c in COUNTERS} for p, run in zip(PATTERNS, runs)}}
+                            "duration_us_per_pattern": dict(zip(PATTERNS, us)),
+                            "duration_spread": (max(us) - min(us)) / min(us) if min(us) > 0 else None,
+                            "busy_cycles_per_pattern": dict(zip(PATTERNS, cyc)),
+                            "busy_cycles_spread": (max(cyc) - min(cyc)) / min(cyc) if min(cyc) > 0 else None,
+                            "clock_ghz_per_pattern": {p: (c / (u * 1e3) if u > 0 else None) for p, c, u in zip(PATTERNS, cyc, us)},
+                            "per_pattern": {p: {c: run.get(c) for c in COUNTERS} for p, run in zip(PATTERNS, runs)},
+                            "differing_dispatches": [] if same else [
+                                {"position": i, "pattern": SEQUENCE[i] if len(runs) == len(SEQUENCE) else None,
+                                 "counters": {c: run.get(c) for c in COUNTERS if run.get(c) != runs[0].get(c)}}
+                                for i, run in enumerate(runs) if any(run.get(c) != runs[0].get(c) for c in COUNTERS)]}
             out["calls"].setdefault(curve, {})[label] = entry
         # the normalisation kernel runs behind every call: its last len(PATTERNS) x len(CALLS) dispatches of this curve are
         # the timed ones (earlier ones belong to the table builds and the base-point batch)
-        norm = [r["c"] for r in mine if "batch_to_affine_unsat" in r["kernel"]][-len(PATTERNS) * len(CALLS):]
+        norm = [r["c"] for r in mine if "batch_to_affine_unsat" in r["kernel"]][-len(SEQUENCE) * len(CALLS):]
         if norm:
             same = all(all(run.get(c) == norm[0].get(c) for c in COUNTERS) for run in norm[1:])
             out["calls"][curve]["normalisation (behind every call above, every pattern)"] = {
@@ -135,6 +152,14 @@ def summarize(root):
                     verdict.append((curve, label, k, e["identical_across_scalar_patterns"]))
             elif label.startswith("normalisation"):
                 verdict.append((curve, label, "k_batch_to_affine_unsat", entry["identical_across_scalar_patterns"]))
+    for curve, calls in out["calls"].items():
+        for label, entry in calls.items():
+            if label.startswith("normalisation"):
+                continue
+            for k, e in entry.items():
+                sys.stderr.write("  %-14s %-32s duration over the scalar patterns: %8.1f .. %8.1f us (spread %.1f %%), busy cycles spread %.1f %%%s\n" % (
+                    curve, label, min(e["duration_us_per_pattern"].values()), max(e["duration_us_per_pattern"].values()),
+                    100 * e["duration_spread"], 100 * (e["busy_cycles_spread"] or 0), "" if label.startswith("ct ") else "   <- control"))
     bad = [v for v in verdict if not v[3]]
     sys.stderr.write(f"secret-scalar kernels checked: {len(verdict)}, with scalar-dependent instruction counts: {len(bad)}\n")
     for v in bad:
