@@ -168,6 +168,7 @@ VARIANT_MULT = {
     ("p384r1_var_2^19", "ct"): _var_unsat(14, 4, 48, 0, 575, 0, merged_y3=True, inv30=(13, 12, 37), wb=4, full_windows=1),
     ("p521r1_var_2^19", "ct"): _var_unsat(18, 0, 66, 0, 780, 0, mont=False, inv30=(18, 18, 51), wb=4, full_windows=3),
     ("bls12_381_g1_var_2^20", "ct"): _var_unsat(14, 14, 32, 1, 570, 0, wb=4, full_windows=64),
+    ("bls12_381_g1_var_2^20", "ctsub"): _var_unsat(14, 14, 32, 1, 570, 0, wb=4, full_windows=1),
     # edwards25519, 86 signed 3-bit windows: 85 x 3 doublings (4 squares + 3 products, the last of a window + 1), 86
     # additions of 6 products, the 4-entry table (1 doubling, 2 additions of 8, 4 x 2d T, to Z = 1: 15 products
     # + one division-step inversion), the normalisation (5 products)
@@ -197,6 +198,9 @@ STEP_KERNELS = {
     # secret scalars: the scanning affine-table ladder, the normalisation, the mirror ladder as fix-up pass
     ("var", "ct"): [["k_scalarmul_coz_unsat<eccx::{U}, eccx::NoGlv, false, false, 4, true>"], ["k_batch_to_affine_unsat<eccx::{U}, 1,"],
                     ["k_scalarmul_var_mirror_unsat<eccx::{U}>"]],
+    # secret scalars, bases vouched to be in the prime-order subgroup (bls12_381_g1)
+    ("var", "ctsub"): [["k_scalarmul_coz_unsat<eccx::{U}, eccx::PrimeOrderBases, false, false, 4, true>"], ["k_batch_to_affine_unsat<eccx::{U}, 1,"],
+                       ["k_scalarmul_var_mirror_unsat<eccx::{U}>"]],
     ("dsm", "default"): [["k_scalarmul_coz_unsat<eccx::{U}, eccx::NoGlv, false, true, 5, false>", "k_scalarmul_coz_unsat<eccx::{U}, eccx::NoGlv, false, true>"],
                          ["k_scalarmul_var_unsat<eccx::{U}, true>"], ["k_batch_to_affine_unsat<eccx::{U}, 1,"]],
     ("dsm", "xonly"): [["k_scalarmul_coz_unsat<eccx::{U}, eccx::NoGlv, false, true, 5, false>"], ["k_scalarmul_var_unsat<eccx::{U}, true>"],
@@ -432,11 +436,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-buffer (PCIe-inclusive) measurement")
     ap.add_argument("--cpu-sample", type=int, default=1 << 17)
-    ap.add_argument("--variant", default="default", choices=["default", "mirror", "lds", "l2", "ct", "ctg", "glv", "xonly"],
+    ap.add_argument("--variant", default="default", choices=["default", "mirror", "lds", "l2", "ct", "ctg", "ctsub", "glv", "xonly"],
                     help="default: fast kernels; mirror: reference-mirroring kernels; "
                          "lds: ed25519 fixed base with a signed 6-bit comb table resident in LDS; "
                          "l2: the reference's 4-bit comb read through L2; "
-                         "ct: ECCX_CT_SCAN (mirror kernels, every table entry read); "
+                         "ct: ECCX_CT_SCAN (secret-scalar kernels, every table entry read); ctg: with ECCX_CT_GATHER; "
+                         "ctsub: ECCX_CT_SCAN | ECCX_ASSUME_SUBGROUP (bls12_381_g1, bases in G1); "
                          "glv: ECCX_ASSUME_SUBGROUP (bls12_381_g1 endomorphism ladder)")
     args = ap.parse_args()
     # ECCX_FORCE_DIST=1: initialise RCCL and run the gather pipeline even at world size 1, so that a
@@ -504,12 +509,12 @@ def main():
     pipe = GatherPipeline(n, out_cols, dev, slots=2, force=force_dist)
 
     mirror = args.variant == "mirror"
-    ct = args.variant in ("ct", "ctg")
+    ct = args.variant in ("ct", "ctg", "ctsub")
     ctg = args.variant == "ctg"
     xonly = args.variant == "xonly"
     if xonly and op != "dsm":
         sys.exit("--variant xonly applies to the verify workloads")
-    glv = args.variant == "glv"
+    glv = args.variant in ("glv", "ctsub")
     # one-time costs out of the timed region (and out of the _dev calls): tables + scratch
     if op in ("base", "dsm"):
         eng.prepare(curve, base=True, base_lds=args.variant == "lds", ct=ct and not ctg, ct_gather=ctg)
@@ -663,7 +668,7 @@ def main():
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": args.workload, "curve": curve, "op": op, "batch_per_gpu": n,
+            "config": {"workload": args.workload, "variant": args.variant, "curve": curve, "op": op, "batch_per_gpu": n,
                        "global_batch": n * world, "parallelism": f"shard{world}" if world > 1 else "single",
                        "gather": "rccl gather to rank 0, overlapped with the next batch (all complete inside the timed region)" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",

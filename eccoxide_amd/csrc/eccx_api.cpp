@@ -168,7 +168,7 @@ int flat_grid(const eccx_ctx* ctx, size_t n) {
 // normalisation where the curve has one.
 int launch_var(eccx_ctx* ctx, const CurveOps* ops, size_t n, const uint8_t* d_scalars, const uint8_t* d_points,
                uint8_t* d_out, uint8_t* d_flags, uint8_t* d_proj, uint32_t kopts, bool mirror, hipStream_t s,
-               bool glv = false, bool ct = false) {
+               bool glv = false, bool ct = false, bool ct_prime = false) {
   if (n == 0) return ECCX_OK;
   if (ct && ops->var_ct && !d_proj && d_points && !(kopts & (K_OUT_TABLE | K_BASE_IS_GENERATOR))) {
     // secret scalars: the windowed ladder that reads every table row at every lookup and resolves its special
@@ -187,7 +187,9 @@ int launch_var(eccx_ctx* ctx, const CurveOps* ops, size_t n, const uint8_t* d_sc
     }
     rc = ensure_rows(ctx, ops, n);
     if (rc) return rc;
-    HIP_TRY(ctx, ops->var_ct(grid, s, n, d_scalars, d_points, ctx->jac, d_flags, ctx->scratch, kopts & ~K_CT_SCAN));
+    // ct_prime: the bases are vouched to have prime order (ECCX_ASSUME_SUBGROUP on a curve with a cofactor)
+    HIP_TRY(ctx, (ct_prime && ops->var_ct_prime ? ops->var_ct_prime : ops->var_ct)(grid, s, n, d_scalars, d_points, ctx->jac, d_flags,
+                                                                                  ctx->scratch, kopts & ~K_CT_SCAN));
     HIP_TRY(ctx, ops->to_affine_var(norm_grid(ctx, n), s, n, ctx->jac, d_out, d_flags));
     if (!ed)
       HIP_TRY(ctx, ops->var(grid2, s, n, d_scalars, d_points, d_out, d_flags, nullptr, ctx->scratch,
@@ -733,17 +735,17 @@ int eccx_scalarmul_var_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_sca
   // ECCX_CT_SCAN: the reference-mirroring ladder (complete formulas, no data-dependent branch) with
   // select_from_table's full scan; edwards25519's mirror ladder is bit-serial and has no table
   const bool ct = (opts & ECCX_CT_SCAN) != 0;
-  if (ct && (opts & ECCX_ASSUME_SUBGROUP)) {
-    ctx->set_err("ECCX_CT_SCAN | ECCX_ASSUME_SUBGROUP: the endomorphism ladder has no secret-scalar form");
-    return ECCX_ERR_ARG;
-  }
+  // ECCX_CT_SCAN | ECCX_ASSUME_SUBGROUP: not the endomorphism ladder (it has no secret-scalar form) but the secret-scalar
+  // ladder with the accumulator == +-entry selects confined to the windows a PRIME-ORDER base can reach, as on the
+  // cofactor-1 curves (bls12_381_g1: -11 % multiplies; what sk * H(m) needs).  No effect on the other curves.
+  const bool subgroup = (opts & ECCX_ASSUME_SUBGROUP) != 0;
   // secret scalars: the scanning affine-table ladder where the curve has one (Weierstrass), unless the
   // reference-mirroring kernels are asked for (ECCX_MIRROR_REFERENCE, proj): those scan as the reference does
   const bool ct_fast = ct && !(opts & ECCX_MIRROR_REFERENCE) && !d_proj && ops->var_ct;
   return launch_var(ctx, ops, n, static_cast<const uint8_t*>(d_scalars), static_cast<const uint8_t*>(d_points),
                     static_cast<uint8_t*>(d_out), static_cast<uint8_t*>(d_flags), static_cast<uint8_t*>(d_proj),
                     kopts_of(opts) | (ct ? K_CT_SCAN : 0u), ct || (opts & ECCX_MIRROR_REFERENCE) != 0, s,
-                    (opts & ECCX_ASSUME_SUBGROUP) != 0, ct_fast);
+                    subgroup && !ct, ct_fast, ct_fast && subgroup);
 }
 
 int eccx_scalarmul_base_dev(eccx_ctx* ctx, int curve, size_t n, const void* d_scalars, void* d_out, void* d_flags,

@@ -13,6 +13,7 @@
 // k_scalarmul_coz_unsat is launched in front of k_scalarmul_var_unsat, which redoes the (rare) units
 // this kernel marks as degenerate.
 #pragma once
+#include <type_traits>
 #include "inv_gcd.hpp"
 #include "kernels_ct.hpp"
 
@@ -22,6 +23,9 @@ namespace eccx {
 struct NoGlv {
   static constexpr int K_BITS = 0;
 };
+// NoGlv for the secret-scalar ladder over bases the caller vouches to have PRIME order (ECCX_CT_SCAN | ECCX_ASSUME_SUBGROUP on
+// a curve with a cofactor): see coz_full_windows()
+struct PrimeOrderBases : NoGlv {};
 
 // ---- scalar split k = k1 + k2 x^2 ----------------------------------------------------------------
 // k: 32 big-endian bytes (any value below 2^256).  k2 = floor(k / x^2) by Barrett with
@@ -287,11 +291,14 @@ ECCX_DEV void ujac_dbl_affine(U<CU, 1, 3>& x3, U<CU, 1, 3>& y3, U<CU, 1, 3>& z3,
 //   what still depends on data: the BASE POINT (public in every protocol the reference implements):
 //               rejected / degenerate units are flagged from the point alone and redone by the
 //               reference-mirroring scan kernel.
-template <class CU, int WB>
+// ASSUME_PRIME: the caller vouches that the bases lie in the subgroup of prime order NBITS bits long (ECCX_CT_SCAN |
+// ECCX_ASSUME_SUBGROUP on bls12_381_g1: a hash-to-curve output, a deserialised and checked point) -- the bound of the
+// prime-order curves then holds there too.
+template <class CU, int WB, bool ASSUME_PRIME = false>
 constexpr int coz_full_windows() {
   using CS = typename CU::Sat;
   constexpr int NWIN = (8 * CS::SB + 1 + WB - 1) / WB;
-  return CS::PRIME_ORDER ? (8 * CS::SB - CS::NBITS + 1) / WB + 1 : NWIN;
+  return (CS::PRIME_ORDER || ASSUME_PRIME) ? (8 * CS::SB - CS::NBITS + 1) / WB + 1 : NWIN;
 }
 #ifndef ECCX_CT_VAR_BITS
 #define ECCX_CT_VAR_BITS 4
@@ -336,6 +343,8 @@ __global__ void __launch_bounds__(WG, (coz_occupancy<CU, GLV>())) k_scalarmul_co
                                                                                  const uint32_t* __restrict__ utable = nullptr) {
   static_assert(!(GLV && FUSED), "the verify shape takes any curve point");
   static_assert(!(CT && (GLV || FUSED)), "the secret-scalar form is the plain ladder");
+  constexpr bool ASSUME_PRIME = std::is_same<G, PrimeOrderBases>::value;
+  static_assert(!ASSUME_PRIME || CT, "PrimeOrderBases only narrows the secret-scalar form's collision windows");
   static_assert(WB >= 3 && WB <= 5, "table rows 1 .. 2^(WB-1) must fit the slab");
   constexpr int TBL = 1 << (WB - 1);  // table rows 1 .. TBL
   using CS = typename CU::Sat;
@@ -483,7 +492,7 @@ __global__ void __launch_bounds__(WG, (coz_occupancy<CU, GLV>())) k_scalarmul_co
     // ---- ladder: per window WB doublings and one mixed addition (two with GLV) ----
     if constexpr (CT) {
       // secret scalars: a fixed schedule, every table row read at every lookup, selects only
-      constexpr int FULLW = coz_full_windows<CU, WB>();
+      constexpr int FULLW = coz_full_windows<CU, WB, ASSUME_PRIME>();
       auto lookup = [&](int w, T& ex, T& ey, uint32_t& d) {
         bool neg;
         booth_digit<WB, SB>(k, w, d, neg);

@@ -148,11 +148,12 @@ enum {
                                       6-bit windows (edwards25519: 5), every entry of the window read by every lane, XYZZ mixed
                                       additions with select-only special cases / complete Edwards additions.  Variable base,
                                       Weierstrass: the affine-table ladder with signed 4-bit windows, all 8 rows of the lane's
-                                      table read at every lookup; edwards25519: the reference's bit-serial double-and-add.  With
+                                      table read at every lookup; edwards25519: signed 3-bit windows over 4 rows normalised to
+                                      Z = 1, complete additions.  With
                                       ECCX_MIRROR_REFERENCE (or proj): the reference-mirroring kernels with select_from_table's
                                       scan (src/curve/projective.rs:427-434, curve25519.rs:862-869).  Same bytes out.
-                                      Not accepted by eccx_double_scalarmul (public data), nor with ECCX_ASSUME_SUBGROUP or
-                                      ECCX_TABLE_IN_LDS. */
+                                      Not accepted by eccx_double_scalarmul (public data), nor with ECCX_TABLE_IN_LDS.
+                                      With ECCX_ASSUME_SUBGROUP see there. */
   ECCX_CT_GATHER = 1u << 10,       /* with ECCX_CT_SCAN, eccx_scalarmul_base: look the window's entry up by a cross-lane
                                       gather (ds_bpermute_b32 from the lane that holds the entry) instead of the scan of the
                                       whole window.  Still no memory address and no branch that depends on a digit; the
@@ -167,7 +168,11 @@ enum {
                                       ECCX_CHECK_SUBGROUP, or is a multiple of the generator).  The
                                       ladder then splits k = k1 + k2*x^2 and uses the endomorphism
                                       sigma(P) = [-x^2]P (src/curve/bls12_381/g1.rs:90-109): half the
-                                      doublings.  For a point outside G1 the result is NOT k*P. */
+                                      doublings.  For a point outside G1 the result is NOT k*P.
+                                      With ECCX_CT_SCAN (secret scalar, base in G1: sk * H(m)) the endomorphism is not
+                                      used; the secret-scalar ladder then resolves "accumulator == +-table entry" only
+                                      in the one window where a base of prime order can reach it, as on the cofactor-1
+                                      curves, instead of in all 64 (11 % fewer multiplies).  Other curves: no effect. */
 };
 
 /* eccx_prepare / eccx_reserve: which one-time costs to pay now */

@@ -37,8 +37,10 @@ pub enum Bases {
     /// Any point of the curve (what the reference's `*` accepts).
     #[default]
     AnyCurvePoint,
-    /// Every point is in the prime-order subgroup G1 (decoded by `from_compressed`, or a multiple of
-    /// the generator): `ECCX_ASSUME_SUBGROUP`, the endomorphism ladder, about 1.4x faster.
+    /// Every point is in the prime-order subgroup G1 (decoded by `from_compressed`, a hash-to-curve output, or a
+    /// multiple of the generator): `ECCX_ASSUME_SUBGROUP`.  Public scalars: the endomorphism ladder, about 1.4x
+    /// faster.  Secret scalars (`sk * H(m)`): the secret-scalar ladder without the per-window handling of bases
+    /// of small order, about 1.1x faster.
     InSubgroup,
 }
 
@@ -54,7 +56,7 @@ pub fn mul_batch(ctx: &GpuContext, points: &[PointAffine], scalars: &[Scalar], b
         push_point(&mut xy, p);
     }
     let mut opts = secrecy.opts_var();
-    if bases == Bases::InSubgroup && secrecy == Secrecy::Public {
+    if bases == Bases::InSubgroup {
         opts |= ffi::ECCX_ASSUME_SUBGROUP;
     }
     let (mut out, mut flags) = (vec![0u8; n * 2 * FB], vec![0u8; n]);

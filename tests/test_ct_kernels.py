@@ -199,6 +199,37 @@ def test_ct_bls_low_order_bases(engine, oracle):
     assert 1 in set(want[1])  # some k is a multiple of a small order
 
 
+def test_ct_bls_subgroup_bases_narrow_ladder(engine, oracle):
+    """ECCX_CT_SCAN | ECCX_ASSUME_SUBGROUP on bls12_381_g1 (sk * H(m)): the secret-scalar ladder that handles
+    accumulator == +-entry only where a base of prime order r can reach it.  Bases in G1, every edge scalar and the
+    scalars that do collide there (k = r, k = 2^256 - 1, ...), whole wavefronts of them, against the oracle."""
+    curve = "bls12_381_g1"
+    fb, sb = _SIZES[curve]
+    vals = _edge_scalars(curve) + sorted(M.collision_scalars_var_base(sb, CT_VAR_BITS, W.order(curve), limit=48))
+    vals += [W.order(curve) * j + d for j in (1, 2) for d in (-2, -1, 0, 1, 2, 8, 16)]
+    vals = [v for v in vals if 0 <= v < (1 << (8 * sb))]
+    ks = _pack(vals, sb)
+    pts = _bases(oracle, curve, len(vals), seed=21)
+    want = oracle.var(curve, ks, pts, threads=16)
+    got = engine.scalarmul_var(curve, ks, pts, ct_scan=True, assume_subgroup=True)
+    assert got == (want[0], want[1])
+    # one scalar per wavefront, 64 different G1 bases each
+    pick = [W.order(curve), W.order(curve) - 1, (1 << 256) - 1, 0, 1]
+    ks = b"".join(_pack([v], sb) * 64 for v in pick)
+    pts = _bases(oracle, curve, 64 * len(pick), seed=22)
+    want = oracle.var(curve, ks, pts, threads=16)
+    assert engine.scalarmul_var(curve, ks, pts, ct_scan=True, assume_subgroup=True) == (want[0], want[1])
+    # 2^16 random units: same bytes as the general secret-scalar ladder
+    n = 1 << 16
+    ks = W.random_scalars(curve, n, seed=23).tobytes()
+    pts = _bases(oracle, curve, n, seed=24)
+    assert engine.scalarmul_var(curve, ks, pts, ct_scan=True, assume_subgroup=True) == engine.scalarmul_var(curve, ks, pts, ct_scan=True)
+    # on a cofactor-1 curve the option changes nothing
+    ks = W.random_scalars("p256r1", 200, seed=25).tobytes()
+    pts = _bases(oracle, "p256r1", 200, seed=26)
+    assert engine.scalarmul_var("p256r1", ks, pts, ct_scan=True, assume_subgroup=True) == engine.scalarmul_var("p256r1", ks, pts, ct_scan=True)
+
+
 @pytest.mark.parametrize("curve", WEI)
 def test_ct_rejected_and_garbage_bases(engine, oracle, curve):
     """ECCX_VALIDATE_POINTS under ECCX_CT_SCAN: rejected records keep flag 2 and zero bytes, and a record that is
@@ -243,10 +274,6 @@ def test_ct_ragged_batches(engine, oracle, curve):
 def test_ct_option_combinations(engine):
     import eccoxide_amd as E
 
-    ks, pts = bytes(32), bytes(96)
-    with pytest.raises(E.EccxError) as ei:
-        engine.scalarmul_var("bls12_381_g1", ks, pts, ct_scan=True, assume_subgroup=True)
-    assert "ASSUME_SUBGROUP" in str(ei.value)
     import ctypes
 
     out, fl = ctypes.create_string_buffer(64), ctypes.create_string_buffer(1)
@@ -267,16 +294,23 @@ def test_engine_level_secrecy_selects_the_secret_scalar_kernels(oracle):
 
     with E.Engine(0, secret_scalars=True) as eng:
         k = W.random_scalars("bls12_381_g1", 70, seed=9).tobytes()
-        pts = _bases(oracle, "bls12_381_g1", 70, 10)
+        pts = _bases(oracle, "bls12_381_g1", 70, seed=10)
         want = oracle.var("bls12_381_g1", k, pts, threads=8)
         assert eng.scalarmul_var("bls12_381_g1", k, pts) == (want[0], want[1])
-        with pytest.raises(E.EccxError) as ei:
-            eng.scalarmul_var("bls12_381_g1", k, pts, assume_subgroup=True)
-        assert "ASSUME_SUBGROUP" in str(ei.value)
         assert eng.scalarmul_var("bls12_381_g1", k, pts, assume_subgroup=True, ct_scan=False) == (want[0], want[1])
         kb = W.random_scalars("ed25519", 70, seed=11).tobytes()
         wb = oracle.base("ed25519", kb, threads=8)
         assert eng.scalarmul_base("ed25519", kb) == (wb[0], wb[1])
+        import torch
+
+        dev = torch.device("cuda", 0)
+        kt = torch.frombuffer(bytearray(kb), dtype=torch.uint8).to(dev)
+        with pytest.raises(E.EccxError) as ei:  # the LDS-resident comb indexes by the digit: refused for secret scalars
+            eng.scalarmul_base_t("ed25519", kt, table_in_lds=True)
+        assert "TABLE_IN_LDS" in str(ei.value)
+        out, fl = eng.scalarmul_base_t("ed25519", kt, table_in_lds=True, ct_scan=False)
+        torch.cuda.synchronize()
+        assert out.cpu().numpy().tobytes() == wb[0]
 
 
 @pytest.mark.parametrize("curve,log2n", [("p256r1", 20), ("ed25519", 20), ("p384r1", 19), ("p521r1", 19), ("bls12_381_g1", 20)])

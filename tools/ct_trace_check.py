@@ -32,9 +32,15 @@ CALLS = [
     ("ct fixed base, scan", dict(base=True, ct_scan=True), ["scalarmul_base_ct<", "batch_to_affine_unsat"]),
     ("ct fixed base, gather", dict(base=True, ct_gather=True), ["scalarmul_base_ct<", "batch_to_affine_unsat"]),
     ("ct variable base", dict(base=False, ct_scan=True), ["scalarmul_coz_unsat<", "ed_scalarmul_var_unsat<", "batch_to_affine_unsat", "var_mirror_unsat"]),
+    # bls12_381_g1 only: bases vouched to be in G1 (ECCX_CT_SCAN | ECCX_ASSUME_SUBGROUP), kernel <..., PrimeOrderBases, ...>
+    ("ct variable base, bases in the subgroup", dict(base=False, ct_scan=True, assume_subgroup=True), ["scalarmul_coz_unsat<"]),
     ("public fixed base (control)", dict(base=True), ["scalarmul_base_unsat<", "batch_to_affine_unsat"]),
     ("public variable base (control)", dict(base=False), ["scalarmul_coz_unsat<", "ed_scalarmul_var_unsat<", "scalarmul_var_unsat<", "batch_to_affine_unsat"]),
 ]
+
+
+def calls_of(curve):
+    return [c for c in CALLS if "assume_subgroup" not in c[1] or curve == "bls12_381_g1"]
 
 
 def scalars(curve, pattern, n):
@@ -71,7 +77,7 @@ def run():
             torch.cuda.synchronize()
             for pattern in PATTERNS + SEQUENCE:  # one untimed pass first: the clock settles before the dispatches that are compared
                 ks = torch.from_numpy(scalars(curve, pattern, N)).to(dev)
-                for label, kw, _ in CALLS:
+                for label, kw, _ in calls_of(curve):
                     kw = dict(kw)
                     if kw.pop("base"):
                         eng.scalarmul_base_t(curve, ks, **kw)
@@ -96,9 +102,10 @@ def summarize(root):
     struct = {"p256r1": "P256U", "p384r1": "P384U", "p521r1": "P521U", "bls12_381_g1": "BLS12_381U", "ed25519": "ED25519U"}
     for curve in CURVES:
         mine = [r for r in order if f"eccx::{struct[curve]}" in r["kernel"] and r["grid"] >= 256]
-        for label, kw, frags in CALLS:
+        for label, kw, frags in calls_of(curve):
             want_ct = "ct_scan" in kw or "ct_gather" in kw
             gather = "ct_gather" in kw
+            subgroup = "assume_subgroup" in kw
             per_kernel = {}
             for r in mine:
                 k = r["kernel"]
@@ -110,6 +117,8 @@ def summarize(root):
                 if want_ct != is_ct_kernel:
                     continue
                 if "scalarmul_base_ct<" in k and (k.endswith(", true>") != gather):
+                    continue
+                if want_ct and "coz_unsat" in k and (("PrimeOrderBases" in k) != subgroup):
                     continue
                 per_kernel.setdefault(k, []).append(dict(r["c"], duration_us=r["us"]))
             entry = {}
@@ -136,7 +145,7 @@ def summarize(root):
             out["calls"].setdefault(curve, {})[label] = entry
         # the normalisation kernel runs behind every call: its last len(PATTERNS) x len(CALLS) dispatches of this curve are
         # the timed ones (earlier ones belong to the table builds and the base-point batch)
-        norm = [r["c"] for r in mine if "batch_to_affine_unsat" in r["kernel"]][-len(SEQUENCE) * len(CALLS):]
+        norm = [r["c"] for r in mine if "batch_to_affine_unsat" in r["kernel"]][-len(SEQUENCE) * len(calls_of(curve)):]
         if norm:
             same = all(all(run.get(c) == norm[0].get(c) for c in COUNTERS) for run in norm[1:])
             out["calls"][curve]["normalisation (behind every call above, every pattern)"] = {

@@ -27,6 +27,8 @@ ROWS = [  # (workload, variant, label)
     ("p521r1_var_2^19", "default", "p521r1 variable base 2^19"),
     ("bls12_381_g1_var_2^20", "default", "bls12_381_g1 variable base 2^20"),
     ("bls12_381_g1_var_2^20", "glv", "bls12_381_g1 variable base 2^20, ECCX_ASSUME_SUBGROUP"),
+    ("bls12_381_g1_var_2^20", "ct", "bls12_381_g1 variable base 2^20, ECCX_CT_SCAN"),
+    ("bls12_381_g1_var_2^20", "ctsub", "bls12_381_g1 variable base 2^20, ECCX_CT_SCAN + ECCX_ASSUME_SUBGROUP"),
     ("ed25519_var_2^20", "default", "ed25519 variable base 2^20"),
     ("ed25519_var_2^20", "ct", "ed25519 variable base 2^20, ECCX_CT_SCAN"),
     ("p256r1_verify_2^20", "default", "p256r1 verify shape 2^20"),
