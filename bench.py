@@ -168,7 +168,9 @@ VARIANT_MULT = {
     ("p384r1_var_2^19", "ct"): _var_unsat(14, 4, 48, 0, 575, 0, merged_y3=True, inv30=(13, 12, 37), wb=4, full_windows=1),
     ("p521r1_var_2^19", "ct"): _var_unsat(18, 0, 66, 0, 780, 0, mont=False, inv30=(18, 18, 51), wb=4, full_windows=3),
     ("bls12_381_g1_var_2^20", "ct"): _var_unsat(14, 14, 32, 1, 570, 0, wb=4, full_windows=64),
-    ("bls12_381_g1_var_2^20", "ctsub"): _var_unsat(14, 14, 32, 1, 570, 0, wb=4, full_windows=1),
+    # the two-half ladder: 33 windows of 4 doublings + 2 additions, beta x per second-half lookup (33 products; the count
+    # of _var_unsat has it per table entry, 8), both additions of the bottom window with the doubled entry
+    ("bls12_381_g1_var_2^20", "ctsub"): {"mad": _var_unsat(14, 14, 32, 1, 570, 0, glv_bits=129, wb=4, full_windows=2)["mad"] + (33 - 8) * 2 * 196, "pair": 0},
     # edwards25519, 86 signed 3-bit windows: 85 x 3 doublings (4 squares + 3 products, the last of a window + 1), 86
     # additions of 6 products, the 4-entry table (1 doubling, 2 additions of 8, 4 x 2d T, to Z = 1: 15 products
     # + one division-step inversion), the normalisation (5 products)
@@ -199,7 +201,7 @@ STEP_KERNELS = {
     ("var", "ct"): [["k_scalarmul_coz_unsat<eccx::{U}, eccx::NoGlv, false, false, 4, true>"], ["k_batch_to_affine_unsat<eccx::{U}, 1,"],
                     ["k_scalarmul_var_mirror_unsat<eccx::{U}>"]],
     # secret scalars, bases vouched to be in the prime-order subgroup (bls12_381_g1)
-    ("var", "ctsub"): [["k_scalarmul_coz_unsat<eccx::{U}, eccx::PrimeOrderBases, false, false, 4, true>"], ["k_batch_to_affine_unsat<eccx::{U}, 1,"],
+    ("var", "ctsub"): [["k_scalarmul_coz_unsat<eccx::{U}, eccx::{G}, true, false, 4, true>"], ["k_batch_to_affine_unsat<eccx::{U}, 1,"],
                        ["k_scalarmul_var_mirror_unsat<eccx::{U}>"]],
     ("dsm", "default"): [["k_scalarmul_coz_unsat<eccx::{U}, eccx::NoGlv, false, true, 5, false>", "k_scalarmul_coz_unsat<eccx::{U}, eccx::NoGlv, false, true>"],
                          ["k_scalarmul_var_unsat<eccx::{U}, true>"], ["k_batch_to_affine_unsat<eccx::{U}, 1,"]],

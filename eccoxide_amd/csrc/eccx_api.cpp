@@ -177,7 +177,8 @@ int launch_var(eccx_ctx* ctx, const CurveOps* ops, size_t n, const uint8_t* d_sc
     // are skipped by the normalisation and redone by the reference-mirroring ladder with the scan (complete
     // formulas), which writes their bytes itself; the complete Edwards formulas have no such units.
     const bool ed = ops->info.edwards != 0;
-    const int grid = ops->var_ct_grid(ctx->cus, n);
+    const bool prime = ct_prime && ops->var_ct_prime;
+    const int grid = prime ? ops->var_ct_prime_grid(ctx->cus, n) : ops->var_ct_grid(ctx->cus, n);
     const int grid2 = std::min(ops->var_grid ? ops->var_grid(ctx->cus, n) : grid_for(ctx, n), ctx->cus);
     int rc = ensure_scratch(ctx, ed ? ops->info.row5_words : ops->coz_row_words, grid);
     if (rc) return rc;
@@ -188,8 +189,8 @@ int launch_var(eccx_ctx* ctx, const CurveOps* ops, size_t n, const uint8_t* d_sc
     rc = ensure_rows(ctx, ops, n);
     if (rc) return rc;
     // ct_prime: the bases are vouched to have prime order (ECCX_ASSUME_SUBGROUP on a curve with a cofactor)
-    HIP_TRY(ctx, (ct_prime && ops->var_ct_prime ? ops->var_ct_prime : ops->var_ct)(grid, s, n, d_scalars, d_points, ctx->jac, d_flags,
-                                                                                  ctx->scratch, kopts & ~K_CT_SCAN));
+    HIP_TRY(ctx, (prime ? ops->var_ct_prime : ops->var_ct)(grid, s, n, d_scalars, d_points, ctx->jac, d_flags, ctx->scratch,
+                                                           kopts & ~K_CT_SCAN));
     HIP_TRY(ctx, ops->to_affine_var(norm_grid(ctx, n), s, n, ctx->jac, d_out, d_flags));
     if (!ed)
       HIP_TRY(ctx, ops->var(grid2, s, n, d_scalars, d_points, d_out, d_flags, nullptr, ctx->scratch,
@@ -697,6 +698,10 @@ int eccx_reserve(eccx_ctx* ctx, int curve, size_t max_n, uint32_t what) {
     const bool ed = ops->info.edwards != 0;
     rc = ensure_scratch(ctx, ed ? ops->info.row5_words : ops->coz_row_words, ops->var_ct_grid(ctx->cus, max_n));
     if (rc) return rc;
+    if (ops->var_ct_prime) {  // ECCX_CT_SCAN | ECCX_ASSUME_SUBGROUP: a kernel of its own, possibly at another occupancy
+      rc = ensure_scratch(ctx, ops->coz_row_words, ops->var_ct_prime_grid(ctx->cus, max_n));
+      if (rc) return rc;
+    }
     if (!ed) {
       const int grid2 = std::min(ops->var_grid ? ops->var_grid(ctx->cus, max_n) : grid_for(ctx, max_n), ctx->cus);
       rc = ensure_scratch(ctx, ops->info.row_words, grid2);

@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(WG, (coz_occupancy<CU, GLV>())) k_scalarmul_co
                                                                                  const uint8_t* __restrict__ base_scalars = nullptr,
                                                                                  const uint32_t* __restrict__ utable = nullptr) {
   static_assert(!(GLV && FUSED), "the verify shape takes any curve point");
-  static_assert(!(CT && (GLV || FUSED)), "the secret-scalar form is the plain ladder");
+  static_assert(!(CT && FUSED), "the verify shape has no secret-scalar form");
   constexpr bool ASSUME_PRIME = std::is_same<G, PrimeOrderBases>::value;
   static_assert(!ASSUME_PRIME || CT, "PrimeOrderBases only narrows the secret-scalar form's collision windows");
   static_assert(WB >= 3 && WB <= 5, "table rows 1 .. 2^(WB-1) must fit the slab");
@@ -456,8 +456,8 @@ __global__ void __launch_bounds__(WG, (coz_occupancy<CU, GLV>())) k_scalarmul_co
       // ---- common denominator zeta = Z_TBL ----
       T lam = one, next = ratio;
       if constexpr (ISO) {
-        if constexpr (GLV) u3_store<CU>(row(TBL), tx, ty, u_fit<1, 3>(u_mul_k<CU>(tx, CU::BETA)));
         if constexpr (CT) u2_store<CU>(crow(TBL), tx, ty);  // the top entry is affine on E' as it stands
+        else if constexpr (GLV) u3_store<CU>(row(TBL), tx, ty, u_fit<1, 3>(u_mul_k<CU>(tx, CU::BETA)));
       } else {
         // 1 / zeta (zeta = 0 only for degenerate units, which are redone anyway: the inverse of 0 is 0)
         Fe<L> c;
@@ -478,8 +478,8 @@ __global__ void __launch_bounds__(WG, (coz_occupancy<CU, GLV>())) k_scalarmul_co
         const T l3 = u_fit<1, 3>(u_mul(l2, lam));
         const T xs = u_fit<1, 3>(u_mul(x, l2));
         const T ys = u_fit<1, 3>(u_mul(y, l3));
-        if constexpr (GLV) u3_store<CU>(row(d), xs, ys, u_fit<1, 3>(u_mul_k<CU>(xs, CU::BETA)));
-        else if constexpr (CT) u2_store<CU>(crow(d), xs, ys);
+        if constexpr (CT) u2_store<CU>(crow(d), xs, ys);
+        else if constexpr (GLV) u3_store<CU>(row(d), xs, ys, u_fit<1, 3>(u_mul_k<CU>(xs, CU::BETA)));
         else u3_store<CU>(row(d), xs, ys, one);
       }
       if constexpr (ISO) {  // zeta = Z_16 / Z_1: the product of all ratios
@@ -491,11 +491,17 @@ __global__ void __launch_bounds__(WG, (coz_occupancy<CU, GLV>())) k_scalarmul_co
 
     // ---- ladder: per window WB doublings and one mixed addition (two with GLV) ----
     if constexpr (CT) {
-      // secret scalars: a fixed schedule, every table row read at every lookup, selects only
-      constexpr int FULLW = coz_full_windows<CU, WB, ASSUME_PRIME>();
-      auto lookup = [&](int w, T& ex, T& ey, uint32_t& d) {
+      // secret scalars: a fixed schedule, every table row read at every lookup, selects only.
+      // With GLV (bases of prime order by contract): two additions per window, the second of [x^2]P = -sigma(P) =
+      // (beta x, -y) computed from the looked-up entry (one product); accumulator == +-entry is possible in the
+      // bottom window only (the partial sums S1 + S2 x^2 are integers below r until the last window is in:
+      // tests/ct_model.py glv_events, exhaustive on small curves of the family).
+      constexpr int FULLW = GLV ? 1 : coz_full_windows<CU, WB, ASSUME_PRIME>();
+      constexpr int HALVES = GLV ? 2 : 1;
+      auto lookup = [&](int w, bool second, T& ex, T& ey, uint32_t& d) {
         bool neg;
-        booth_digit<WB, SB>(k, w, d, neg);
+        booth(w, second, d, neg);
+        neg = neg != second;  // `second` is the same for every lane
         u_set_zero(ex);
         u_set_zero(ey);
 #pragma unroll 2
@@ -505,6 +511,9 @@ __global__ void __launch_bounds__(WG, (coz_occupancy<CU, GLV>())) k_scalarmul_co
           const uint64_t m = __builtin_amdgcn_uicmp(d, (uint32_t)j, 32 /* ICMP_EQ */);
           u_cmov_ct(ex, m, cx);
           u_cmov_ct(ey, m, cy);
+        }
+        if constexpr (GLV) {
+          if (second) ex = u_fit<1, 3>(u_mul_k<CU>(ex, CU::BETA));
         }
         U<CU, 2, 4> sy;
         u_select_ct(sy, neg, u_neg(ey), u_as<2, 4>(ey));
@@ -518,45 +527,50 @@ __global__ void __launch_bounds__(WG, (coz_occupancy<CU, GLV>())) k_scalarmul_co
         // infinity for digit 0
         T ex, ey;
         uint32_t d;
-        lookup(NWIN - 1, ex, ey, d);
+        lookup(NWIN - 1, false, ex, ey, d);
         q.x = ex;
         q.y = ey;
         u_select_ct(q.z, d == 0, u_as<UJac<CU>::ZK, UJac<CU>::ZV>(zero), u_as<UJac<CU>::ZK, UJac<CU>::ZV>(one));
       }
 #pragma unroll 1
-      for (int win = NWIN - 2; win >= 0; --win) {
+      for (int win = NWIN - 1; win >= 0; --win) {
+        if (win != NWIN - 1) {
 #pragma unroll 1
-        for (int j = 0; j < WB; ++j) {
-          UJac<CU> t;
-          ujac_dbl<CU>(t, q);
-          q = t;
+          for (int j = 0; j < WB; ++j) {
+            UJac<CU> t;
+            ujac_dbl<CU>(t, q);
+            q = t;
+          }
         }
-        T ex, ey;
-        uint32_t d;
-        lookup(win, ex, ey, d);
-        const bool q_inf = u_limbs_all_zero(q.z);
-        const bool e_skip = d == 0;
-        UJac<CU> sum;
-        bool hz, rz;
-        ujac_madd_ct<CU>(sum, hz, rz, q, ex, ey);
-        if (win < FULLW) {  // loop counter: the same for every lane and every scalar
-          T dx, dy, dz, sv, y8v;
-          ujac_dbl_affine<CU>(dx, dy, dz, sv, y8v, ex, ey);
-          const bool same_x = hz & !q_inf & !e_skip;
-          const uint64_t mt = ct_mask(same_x & rz);    // accumulator == entry
-          const uint64_t mc = ct_mask(same_x & !rz);   // accumulator == -entry
-          u_cmov_ct(sum.x, mt, dx);
-          u_cmov_ct(sum.y, mt, dy);
-          u_cmov_ct(sum.z, mt, TZ(u_as<UJac<CU>::ZK, UJac<CU>::ZV>(dz)));
-          u_cmov_ct(sum.z, mc, TZ(u_as<UJac<CU>::ZK, UJac<CU>::ZV>(zero)));
+#pragma unroll 1
+        for (int half = (win == NWIN - 1) ? 1 : 0; half < HALVES; ++half) {
+          T ex, ey;
+          uint32_t d;
+          lookup(win, half != 0, ex, ey, d);
+          const bool q_inf = u_limbs_all_zero(q.z);
+          const bool e_skip = d == 0;
+          UJac<CU> sum;
+          bool hz, rz;
+          ujac_madd_ct<CU>(sum, hz, rz, q, ex, ey);
+          if (win < FULLW) {  // loop counter: the same for every lane and every scalar
+            T dx, dy, dz, sv, y8v;
+            ujac_dbl_affine<CU>(dx, dy, dz, sv, y8v, ex, ey);
+            const bool same_x = hz & !q_inf & !e_skip;
+            const uint64_t mt = ct_mask(same_x & rz);    // accumulator == entry
+            const uint64_t mc = ct_mask(same_x & !rz);   // accumulator == -entry
+            u_cmov_ct(sum.x, mt, dx);
+            u_cmov_ct(sum.y, mt, dy);
+            u_cmov_ct(sum.z, mt, TZ(u_as<UJac<CU>::ZK, UJac<CU>::ZV>(dz)));
+            u_cmov_ct(sum.z, mc, TZ(u_as<UJac<CU>::ZK, UJac<CU>::ZV>(zero)));
+          }
+          const uint64_t mi = ct_mask(q_inf), mk = ct_mask(!e_skip);
+          u_cmov_ct(sum.x, mi, ex);  // accumulator at infinity: the sum is the entry
+          u_cmov_ct(sum.y, mi, ey);
+          u_cmov_ct(sum.z, mi, TZ(u_as<UJac<CU>::ZK, UJac<CU>::ZV>(one)));
+          u_cmov_ct(q.x, mk, sum.x);
+          u_cmov_ct(q.y, mk, sum.y);
+          u_cmov_ct(q.z, mk, sum.z);
         }
-        const uint64_t mi = ct_mask(q_inf), mk = ct_mask(!e_skip);
-        u_cmov_ct(sum.x, mi, ex);  // accumulator at infinity: the sum is the entry
-        u_cmov_ct(sum.y, mi, ey);
-        u_cmov_ct(sum.z, mi, TZ(u_as<UJac<CU>::ZK, UJac<CU>::ZV>(one)));
-        u_cmov_ct(q.x, mk, sum.x);
-        u_cmov_ct(q.y, mk, sum.y);
-        u_cmov_ct(q.z, mk, sum.z);
       }
     } else {
       constexpr int LAST_SUB = GLV ? WB + 1 : WB;  // sub 0..WB-1: doublings, WB: addition (WB+1: second half's addition)

@@ -118,6 +118,7 @@ struct CurveOps {
   // accumulator == +-entry selects only in the windows a prime-order point can reach; null where the curve has no cofactor
   hipError_t (*var_ct_prime)(int grid, hipStream_t s, size_t n, const uint8_t* scalars, const uint8_t* points, uint32_t* rows,
                              uint8_t* flags, uint32_t* scratch, uint32_t opts);
+  int (*var_ct_prime_grid)(int cus, size_t n);
   // normalisation of Jacobian rows to the x-coordinate alone, FB bytes per unit (ECCX_OUT_X_ONLY; Weierstrass)
   hipError_t (*to_affine_x)(int grid, hipStream_t s, size_t n, const uint32_t* rows, uint8_t* out, uint8_t* flags);
 };

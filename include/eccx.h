@@ -169,10 +169,11 @@ enum {
                                       ladder then splits k = k1 + k2*x^2 and uses the endomorphism
                                       sigma(P) = [-x^2]P (src/curve/bls12_381/g1.rs:90-109): half the
                                       doublings.  For a point outside G1 the result is NOT k*P.
-                                      With ECCX_CT_SCAN (secret scalar, base in G1: sk * H(m)) the endomorphism is not
-                                      used; the secret-scalar ladder then resolves "accumulator == +-table entry" only
-                                      in the one window where a base of prime order can reach it, as on the cofactor-1
-                                      curves, instead of in all 64 (11 % fewer multiplies).  Other curves: no effect. */
+                                      With ECCX_CT_SCAN (secret scalar, base in G1: sk * H(m)) the same split runs in
+                                      secret-scalar form: branch-free split, every table row read at both lookups of a
+                                      window, "accumulator == +-table entry" resolved by selects in the one window
+                                      where a base of prime order can reach it (1.6x faster than ECCX_CT_SCAN alone).
+                                      Other curves: no effect. */
 };
 
 /* eccx_prepare / eccx_reserve: which one-time costs to pay now */

@@ -39,8 +39,8 @@ pub enum Bases {
     AnyCurvePoint,
     /// Every point is in the prime-order subgroup G1 (decoded by `from_compressed`, a hash-to-curve output, or a
     /// multiple of the generator): `ECCX_ASSUME_SUBGROUP`.  Public scalars: the endomorphism ladder, about 1.4x
-    /// faster.  Secret scalars (`sk * H(m)`): the secret-scalar ladder without the per-window handling of bases
-    /// of small order, about 1.1x faster.
+    /// faster.  Secret scalars (`sk * H(m)`): the same ladder in secret-scalar form (every table row read, selects
+    /// only), about 1.6x faster than for arbitrary curve points.
     InSubgroup,
 }
 

@@ -113,3 +113,68 @@ def collision_scalars_var_base(sb: int, wb: int, n: int, limit: int = 64):
                     if len(found) >= limit:
                         return found
     return found
+
+
+# ---- the endomorphism ladder with secret scalars (kernels_coz.hpp, GLV = true, CT = true; bls12_381_g1) -------------
+def glv_digits(v: int, nwin: int, wb: int):
+    """Booth digits of one half of the split scalar over nwin windows (the booth lambda of the kernel)."""
+    out = []
+    for i in range(nwin):
+        wv = ((v << 1) >> (wb * i)) & ((1 << (wb + 1)) - 1)
+        neg = wv >> wb
+        m = ((1 << (wb + 1)) - wv - 1) if neg else wv
+        d = (m >> 1) + (m & 1)
+        out.append(-d if neg else d)
+    assert sum(d << (wb * i) for i, d in enumerate(out)) == v, "the half must fit nwin windows"
+    return out
+
+
+def glv_events(k: int, x2: int, r: int, kbits: int, wb: int):
+    """k = k1 + k2 x^2 (k2 = floor(k / x^2)); [x^2]P = -sigma(P) is one table lookup away.  The ladder: accumulator =
+    top digit of k1, + top digit of k2 times x^2; per window (HIGH to LOW) wb doublings, + d1, + d2 x^2.  Returns
+    [(window, half, 'twice' | 'cancel')] for every addition whose entry meets an accumulator equal to +- it (mod r)
+    while neither is the neutral element."""
+    k2, k1 = divmod(k, x2)
+    nwin = (kbits + 1 + wb - 1) // wb
+    d1s, d2s = glv_digits(k1, nwin, wb), glv_digits(k2, nwin, wb)
+    ev = []
+    s = 0
+
+    def add(win, half, e):
+        nonlocal s
+        if e % r != 0 and s % r != 0:
+            if (s - e) % r == 0:
+                ev.append((win, half, "twice"))
+            elif (s + e) % r == 0:
+                ev.append((win, half, "cancel"))
+        s += e
+
+    for win in range(nwin - 1, -1, -1):
+        if win != nwin - 1:
+            s <<= wb
+        add(win, 0, d1s[win])
+        add(win, 1, d2s[win] * x2)
+    assert s == k
+    return ev
+
+
+BLS_X = 0xD201000000010000  # |x| of BLS12-381; r = x^4 - x^2 + 1
+BLS_X2 = BLS_X * BLS_X
+BLS_R = BLS_X2 * BLS_X2 - BLS_X2 + 1
+
+
+def collision_scalars_glv(x2: int, r: int, sbits: int, kbits: int, wb: int, limit: int = 48):
+    """Scalars below 2^sbits whose endomorphism ladder hits a collision select: k = j r + a + b x^2 for small a, b."""
+    found = {}
+    span = (1 << (wb - 1)) * 2 + 1
+    for j in range(1, 1 + (1 << sbits) // r):
+        for b in range(-span, span + 1):
+            for a in range(-span, span + 1):
+                k = j * r + a + b * x2
+                if 0 < k < (1 << sbits) and k not in found:
+                    ev = glv_events(k, x2, r, kbits, wb)
+                    if ev:
+                        found[k] = ev
+                        if len(found) >= limit:
+                            return found
+    return found

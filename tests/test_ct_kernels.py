@@ -207,6 +207,9 @@ def test_ct_bls_subgroup_bases_narrow_ladder(engine, oracle):
     fb, sb = _SIZES[curve]
     vals = _edge_scalars(curve) + sorted(M.collision_scalars_var_base(sb, CT_VAR_BITS, W.order(curve), limit=48))
     vals += [W.order(curve) * j + d for j in (1, 2) for d in (-2, -1, 0, 1, 2, 8, 16)]
+    glv = M.collision_scalars_glv(M.BLS_X2, M.BLS_R, 256, 129, CT_VAR_BITS)  # the two-half ladder's own collisions
+    assert {kind for ev in glv.values() for _, _, kind in ev} == {"twice", "cancel"}
+    vals += sorted(glv) + [k + d * M.BLS_X2 for k in (M.BLS_R, 2 * M.BLS_R) for d in (-8, -1, 1, 7, 8)] + [M.BLS_X2 - 1, M.BLS_X2, M.BLS_X2 + 1, 8 * M.BLS_X2, (M.BLS_X2 << 128) % (1 << 256)]
     vals = [v for v in vals if 0 <= v < (1 << (8 * sb))]
     ks = _pack(vals, sb)
     pts = _bases(oracle, curve, len(vals), seed=21)
@@ -214,7 +217,7 @@ def test_ct_bls_subgroup_bases_narrow_ladder(engine, oracle):
     got = engine.scalarmul_var(curve, ks, pts, ct_scan=True, assume_subgroup=True)
     assert got == (want[0], want[1])
     # one scalar per wavefront, 64 different G1 bases each
-    pick = [W.order(curve), W.order(curve) - 1, (1 << 256) - 1, 0, 1]
+    pick = [W.order(curve), W.order(curve) - 1, (1 << 256) - 1, 0, 1] + sorted(glv)
     ks = b"".join(_pack([v], sb) * 64 for v in pick)
     pts = _bases(oracle, curve, 64 * len(pick), seed=22)
     want = oracle.var(curve, ks, pts, threads=16)

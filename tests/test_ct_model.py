@@ -130,3 +130,30 @@ def test_tagged_limbs_survive_the_floating_point_select():
         assert np.all(nothing.view(np.uint32) == 0)
     assert np.array_equal(after.view(np.uint32) & ~TAG, limbs)              # the tag comes off
     assert np.all((nothing.view(np.uint32) & ~TAG) == 0)
+
+
+@pytest.mark.parametrize("x", [10, 12])
+@pytest.mark.parametrize("wb", [3, 4, 5])
+def test_glv_ladder_collisions_stay_in_the_bottom_window(x, wb):
+    """The endomorphism ladder under ECCX_CT_SCAN | ECCX_ASSUME_SUBGROUP (kernels_coz.hpp, GLV and CT) resolves
+    accumulator == +-entry in window 0 only.  Exhaustive on two small members of the BLS12 family (r = x^4 - x^2 + 1
+    prime, the scalar range 3.2-3.3 r where the real curve has 2.2 r): every scalar, every addition."""
+    r = x**4 - x * x + 1
+    assert all(r % q for q in range(2, int(r**0.5) + 1))
+    x2 = x * x
+    sbits = r.bit_length() + 1
+    kbits = (((1 << sbits) - 1) // x2).bit_length()
+    seen = set()
+    for k in range(1 << sbits):
+        for win, half, kind in M.glv_events(k, x2, r, kbits, wb):
+            assert win == 0, (k, win, half, kind)
+            seen.add(kind)
+    assert seen == {"twice", "cancel"}
+
+
+def test_real_bls12_381_glv_collision_scalars():
+    found = M.collision_scalars_glv(M.BLS_X2, M.BLS_R, 256, 129, 4)
+    assert M.BLS_R in found and 2 * M.BLS_R in found                     # k = r, 2 r: the last addition cancels
+    kinds = {kind for ev in found.values() for _, _, kind in ev}
+    assert kinds == {"twice", "cancel"}
+    assert all(win == 0 for ev in found.values() for win, _, _ in ev)

@@ -32,7 +32,7 @@ CALLS = [
     ("ct fixed base, scan", dict(base=True, ct_scan=True), ["scalarmul_base_ct<", "batch_to_affine_unsat"]),
     ("ct fixed base, gather", dict(base=True, ct_gather=True), ["scalarmul_base_ct<", "batch_to_affine_unsat"]),
     ("ct variable base", dict(base=False, ct_scan=True), ["scalarmul_coz_unsat<", "ed_scalarmul_var_unsat<", "batch_to_affine_unsat", "var_mirror_unsat"]),
-    # bls12_381_g1 only: bases vouched to be in G1 (ECCX_CT_SCAN | ECCX_ASSUME_SUBGROUP), kernel <..., PrimeOrderBases, ...>
+    # bls12_381_g1 only: bases vouched to be in G1 (ECCX_CT_SCAN | ECCX_ASSUME_SUBGROUP), the two-half ladder <..., BLS12_381_GLV, true, ...>
     ("ct variable base, bases in the subgroup", dict(base=False, ct_scan=True, assume_subgroup=True), ["scalarmul_coz_unsat<"]),
     ("public fixed base (control)", dict(base=True), ["scalarmul_base_unsat<", "batch_to_affine_unsat"]),
     ("public variable base (control)", dict(base=False), ["scalarmul_coz_unsat<", "ed_scalarmul_var_unsat<", "scalarmul_var_unsat<", "batch_to_affine_unsat"]),
@@ -118,7 +118,7 @@ def summarize(root):
                     continue
                 if "scalarmul_base_ct<" in k and (k.endswith(", true>") != gather):
                     continue
-                if want_ct and "coz_unsat" in k and (("PrimeOrderBases" in k) != subgroup):
+                if want_ct and "coz_unsat" in k and (("PrimeOrderBases" in k or "_GLV" in k) != subgroup):
                     continue
                 per_kernel.setdefault(k, []).append(dict(r["c"], duration_us=r["us"]))
             entry = {}

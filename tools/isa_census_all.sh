@@ -22,7 +22,7 @@ for spec in "k_p256 p256r1 P256U NoGlv" "k_p384 p384r1 P384U NoGlv" "k_p521 p521
   emit $1 $2 "k_scalarmul_base_ct<eccx::$3, true>" gather
   emit $1 $2 "k_scalarmul_coz_unsat<eccx::$3, eccx::$4, false, false, 4, true>" var
 done
-emit k_bls12_381 bls12_381_g1 "k_scalarmul_coz_unsat<eccx::BLS12_381U, eccx::PrimeOrderBases, false, false, 4, true>" var_subgroup
+emit k_bls12_381 bls12_381_g1 "k_scalarmul_coz_unsat<eccx::BLS12_381U, eccx::BLS12_381_GLV, true, false, 4, true>" var_subgroup
 emit k_ed25519 ed25519 "k_ed_scalarmul_base_ct<eccx::ED25519U, false>" base
 emit k_ed25519 ed25519 "k_ed_scalarmul_base_ct<eccx::ED25519U, true>" gather
 emit k_ed25519 ed25519 "k_ed_scalarmul_var_unsat<eccx::ED25519U, false, 3, true>" var
