@@ -85,6 +85,9 @@ def main():
             # sixth round the reference-mirroring kernels with the scan
             v_ct, vf_ct = eng.scalarmul_var_t(curve, k2, b_def, ct_scan=True)
             assert torch.equal(v_ct, v_def) and torch.equal(vf_ct, vf_def), ("ct var", curve, n, rounds)
+            if curve == "bls12_381_g1":  # bases in G1: the endomorphism ladder in secret-scalar form
+                v_cs, vf_cs = eng.scalarmul_var_t(curve, k2, b_def, ct_scan=True, assume_subgroup=True)
+                assert torch.equal(v_cs, v_def) and torch.equal(vf_cs, vf_def), ("ct subgroup var", curve, n, rounds)
             b_ct, f_ct = eng.scalarmul_base_t(curve, k1, ct_scan=True)
             assert torch.equal(b_ct, b_mir) and torch.equal(f_ct, f_mir), ("ct base", curve, n, rounds)
             b_cg, f_cg = eng.scalarmul_base_t(curve, k1, ct_gather=True)
