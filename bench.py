@@ -638,7 +638,7 @@ def main():
             pw_out, pw_inf = expected(p_k, p_k2, p_pts)
             pidx = idx + peer * n
             parity = parity and (g_out[pidx].cpu().numpy().tobytes() == pw_out) and (g_flags[pidx].cpu().numpy().tobytes() == pw_inf)
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:  # a reported baseline, timed at N = 1 only (the other ranks would wait)
             cpu = cpu_baseline(ora, curve, op, args, n, ks, ks2, pts)
         if world == 1 and not args.no_host_path and op in ("var", "base"):
             host = host_path(eng, curve, op, n, ks, pts, out, opts_bits)
