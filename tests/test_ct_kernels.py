@@ -256,6 +256,15 @@ def test_ct_rejected_and_garbage_bases(engine, oracle, curve):
     for i in range(n):
         if i not in bad:
             assert got2[0][i * 2 * fb:(i + 1) * 2 * fb] == want[0][i * 2 * fb:(i + 1) * 2 * fb]
+    if curve == "bls12_381_g1":  # the same through the secret-scalar endomorphism ladder (the good bases are in G1)
+        got3 = engine.scalarmul_var(curve, ks, pts, ct_scan=True, assume_subgroup=True, validate=True)
+        got4 = engine.scalarmul_var(curve, ks, pts, ct_scan=True, assume_subgroup=True)
+        for i in range(n):
+            if i in bad:
+                assert got3[1][i] == 2 and got3[0][i * 2 * fb:(i + 1) * 2 * fb] == bytes(2 * fb)
+            else:
+                assert got3[1][i] == want[1][i] and got3[0][i * 2 * fb:(i + 1) * 2 * fb] == want[0][i * 2 * fb:(i + 1) * 2 * fb]
+                assert got4[0][i * 2 * fb:(i + 1) * 2 * fb] == want[0][i * 2 * fb:(i + 1) * 2 * fb]
 
 
 @pytest.mark.parametrize("curve", ALL)
