@@ -49,11 +49,14 @@ int main() {
       if (ct.device_bytes() == 0) { std::puts("FAIL: prepare left the context empty"); return 1; }
       auto sbase = eccx::Points<C>::mul_base(ct, scalars);
       auto svar = eccx::on(ct, gen) * scalars;
+      // ECCX_ASSUME_SUBGROUP is accepted beside ECCX_CT_SCAN (a no-op on this cofactor-1 curve)
+      auto ssub = gen.mul(ct, scalars, /*validate=*/false, eccx::Bases::InSubgroup).to_affine();
       const auto& sb = sbase.to_affine();
       const auto& sv = svar.to_affine();
       for (size_t i = 0; i < n; ++i) {
         if (sb.is_infinity(i) != a.is_infinity(i) || std::memcmp(sb.x(i), a.x(i), 64) ||
-            sv.is_infinity(i) != a.is_infinity(i) || std::memcmp(sv.x(i), a.x(i), 64)) {
+            sv.is_infinity(i) != a.is_infinity(i) || std::memcmp(sv.x(i), a.x(i), 64) ||
+            ssub.is_infinity(i) != a.is_infinity(i) || std::memcmp(ssub.x(i), a.x(i), 64)) {
           std::printf("FAIL: scanning kernels differ at %zu\n", i);
           return 1;
         }
