@@ -491,6 +491,12 @@ def test_full_size_other_curves(engine, oracle, curve, n):
     _full_size_check(engine, oracle, curve, n, seed=3000 + n)
 
 
+def test_whole_config_3_batch_on_one_gpu(engine, oracle):
+    """BASELINE.json configs[3] is 2^22 p384r1 units over 8 GPUs; the whole batch also fits ONE GPU (1 GB of
+    inputs and outputs, 0.6 GB of window tables): the same size-independent check at 2^22, eight times the per-GPU share."""
+    _full_size_check(engine, oracle, "p384r1", 1 << 22, seed=7000)
+
+
 def test_two_contexts_on_two_streams(oracle):
     """Contexts are independent (own scratch slab and tables): two of them driven from two
     HIP streams at once give the same bytes as one after the other."""
