@@ -473,9 +473,11 @@ int run_host(eccx_ctx* ctx, int curve, bool base, size_t n, const uint8_t* scala
   // beside the kernels of chunk i: three streams, events between them.  The host buffers are
   // pageable, so each copy call returns when its data has been staged; the kernels it overlaps
   // with are already enqueued.
-  // (variable base only: measured 20.8 -> 19.3 ms for 2^20 p256 units; the fixed-base kernels are
-  // shorter than their copies and lose to the per-chunk launch costs: 3.4 -> 4.5 ms)
-  const size_t nchunks = (!proj && !base && n >= ((size_t)1 << 17)) ? 4 : 1;
+  // (variable base: measured 20.8 -> 19.3 ms for 2^20 p256 units; the public-scalar fixed-base kernels are
+  // shorter than their copies and lose to the per-chunk launch costs: 3.4 -> 4.5 ms; the secret-scalar combs
+  // are longer than their copies and take the chunks)
+  const bool chunked = !base || ((opts & ECCX_CT_SCAN) && !(opts & (ECCX_MIRROR_REFERENCE | ECCX_TABLE_IN_L2)));
+  const size_t nchunks = (!proj && chunked && n >= ((size_t)1 << 17)) ? 4 : 1;
   static_assert(2 * 4 <= eccx_ctx::NEV, "two events per chunk");
   const size_t step = ((n + nchunks - 1) / nchunks + 4095) / 4096 * 4096;
   // a single chunk keeps everything on the compute stream (crossing streams costs ~1 ms of idle gaps)
