@@ -342,7 +342,7 @@ def _usable_cores():
     return n
 
 
-def host_path(eng, curve, op, n, ks, pts, dev_out, opts_bits):
+def host_path(eng, curve, op, n, ks, pts, dev_out, opts_bits, ks2=None):
     """The same batch through the HOST-buffer entry point (what a caller without device buffers -- the Rust crate --
     uses): pageable host memory in, pageable host memory out, PCIe copies and the final synchronisation included.
     Never part of `value` (reported separately).  The first call sizes the context's device-side
@@ -356,8 +356,9 @@ def host_path(eng, curve, op, n, ks, pts, dev_out, opts_bits):
     cid, fb, sb = E.curve_id(curve), E.field_bytes(curve), E.scalar_bytes(curve)
     lib, ctx = eng._lib, eng._ctx
     hk = np.ascontiguousarray(ks.cpu().numpy())
-    hp = np.ascontiguousarray(pts.cpu().numpy()) if op == "var" else None
-    ho = np.empty((n, 2 * fb), dtype=np.uint8)
+    hk2 = np.ascontiguousarray(ks2.cpu().numpy()) if op == "dsm" else None
+    hp = np.ascontiguousarray(pts.cpu().numpy()) if op in ("var", "dsm", "x25519") else None
+    ho = np.empty(tuple(dev_out.shape), dtype=np.uint8)
     hf = np.empty((n,), dtype=np.uint8)
     eng.reserve(curve, n, var=False, host=True)
 
@@ -365,6 +366,10 @@ def host_path(eng, curve, op, n, ks, pts, dev_out, opts_bits):
         t = time.perf_counter()
         if op == "var":
             rc = lib.eccx_scalarmul_var(ctx, cid, n, hk.ctypes.data, hp.ctypes.data, ho.ctypes.data, hf.ctypes.data, None, opts_bits)
+        elif op == "dsm":
+            rc = lib.eccx_double_scalarmul(ctx, cid, n, hk.ctypes.data, hk2.ctypes.data, hp.ctypes.data, ho.ctypes.data, hf.ctypes.data, opts_bits)
+        elif op == "x25519":
+            rc = lib.eccx_x25519(ctx, n, hk.ctypes.data, hp.ctypes.data, ho.ctypes.data, hf.ctypes.data, 0)
         else:
             rc = lib.eccx_scalarmul_base(ctx, cid, n, hk.ctypes.data, ho.ctypes.data, hf.ctypes.data, None, opts_bits)
         dt = time.perf_counter() - t
@@ -374,9 +379,9 @@ def host_path(eng, curve, op, n, ks, pts, dev_out, opts_bits):
     call()
     best = min(call() for _ in range(3))
     same = bool((ho == dev_out.cpu().numpy()).all())
-    pcie = n * (sb + (2 * fb if op == "var" else 0)) + n * (2 * fb + 1)
+    pcie = int(hk.nbytes + (hk2.nbytes if hk2 is not None else 0) + (hp.nbytes if hp is not None else 0) + ho.nbytes + hf.nbytes)
     return {"ms": best * 1e3, "units_per_s": n / best, "pcie_bytes": pcie, "matches_device_run": same,
-            "entry_point": "eccx_scalarmul_var" if op == "var" else "eccx_scalarmul_base",
+            "entry_point": {"var": "eccx_scalarmul_var", "dsm": "eccx_double_scalarmul", "x25519": "eccx_x25519"}.get(op, "eccx_scalarmul_base"),
             "note": "host-buffer call on the same batch: pageable host memory, H2D + kernels + D2H + synchronisation; "
                     "not part of value (tools/hostbench: the same measurement from C, profiles/r03_hostbench.jsonl)"}
 
@@ -640,8 +645,8 @@ def main():
             parity = parity and (g_out[pidx].cpu().numpy().tobytes() == pw_out) and (g_flags[pidx].cpu().numpy().tobytes() == pw_inf)
         if world == 1 and not args.no_cpu_baseline:  # a reported baseline, timed at N = 1 only (the other ranks would wait)
             cpu = cpu_baseline(ora, curve, op, args, n, ks, ks2, pts)
-        if world == 1 and not args.no_host_path and op in ("var", "base"):
-            host = host_path(eng, curve, op, n, ks, pts, out, opts_bits)
+        if world == 1 and not args.no_host_path:
+            host = host_path(eng, curve, op, n, ks, pts, out, opts_bits | (E.engine.OUT_X_ONLY if xonly else 0), ks2)
 
     if rank == 0:
         total_units = n * world * args.steps

@@ -450,34 +450,24 @@ uint32_t kopts_of(uint32_t opts) { return (opts & ECCX_VALIDATE_POINTS) ? K_VALI
 
 size_t proj_bytes(const CurveOps* ops) { return (size_t)(ops->info.edwards ? 4 : 3) * ops->info.fb; }
 
-// host-buffer wrapper shared by var / base.  Device-side copies of the caller's buffers live in the context's
-// I/O slots (grow-only: nothing is allocated or freed once a batch of this size has been seen, or after
-// eccx_reserve(..., ECCX_PREP_HOST)), the events come from the context's pool.
-int run_host(eccx_ctx* ctx, int curve, bool base, size_t n, const uint8_t* scalars, const uint8_t* points,
-             uint8_t* out, uint8_t* flags, uint8_t* proj, uint32_t opts) {
-  const CurveOps* ops = ops_of(curve);
-  if (!ctx) return ECCX_ERR_ARG;
-  if (!ops) return curve_err(ctx);
-  if (n == 0) return ECCX_OK;
-  if (!scalars || !out || !flags || (!base && !points)) return arg_err(ctx, "null buffer");
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  size_t sb = ops->info.sb, pb = 2 * (size_t)ops->info.fb;
-  uint8_t *d_k = nullptr, *d_p = nullptr, *d_o = nullptr, *d_f = nullptr, *d_j = nullptr;
-  int rc = ensure_io(ctx, IO_K, n * sb, &d_k);
-  if (!rc) rc = ensure_io(ctx, IO_O, n * pb, &d_o);
-  if (!rc) rc = ensure_io(ctx, IO_F, n, &d_f);
-  if (!rc && !base) rc = ensure_io(ctx, IO_P, n * pb, &d_p);
-  if (!rc && proj) rc = ensure_io(ctx, IO_J, n * proj_bytes(ops), &d_j);
-  if (rc) return rc;
-  // Large batches go through in chunks so that the PCIe copies of chunk i+1 (in) and i-1 (out) run
-  // beside the kernels of chunk i: three streams, events between them.  The host buffers are
-  // pageable, so each copy call returns when its data has been staged; the kernels it overlaps
-  // with are already enqueued.
-  // (variable base: measured 20.8 -> 19.3 ms for 2^20 p256 units; the public-scalar fixed-base kernels are
-  // shorter than their copies and lose to the per-chunk launch costs: 3.4 -> 4.5 ms; the secret-scalar combs
-  // are longer than their copies and take the chunks)
-  const bool chunked = !base || ((opts & ECCX_CT_SCAN) && !(opts & (ECCX_MIRROR_REFERENCE | ECCX_TABLE_IN_L2)));
-  const size_t nchunks = (!proj && chunked && n >= ((size_t)1 << 17)) ? 4 : 1;
+// ---- host-buffer entry points: copies in, kernels, copies out ------------------------------------------------
+// Device-side copies of the caller's buffers live in the context's I/O slots (grow-only: nothing is allocated or
+// freed once a batch of this size has been seen, or after eccx_reserve(..., ECCX_PREP_HOST)), the events come from
+// the context's pool.
+struct HostIn { uint8_t* dev; const uint8_t* host; size_t width; };   // width: bytes per unit
+struct HostOut { uint8_t* host; const uint8_t* dev; size_t width; };
+
+// Large batches go through in chunks so that the PCIe copies of chunk i+1 (in) and i-1 (out) run beside the
+// kernels of chunk i: three streams, events between them.  The host buffers are pageable, so each copy call
+// returns when its data has been staged; the kernels it overlaps with are already enqueued.  `chunked` is the
+// caller's judgement that the kernels outlast the copies (variable base: 20.8 -> 19.3 ms for 2^20 p256 units; the
+// public-scalar fixed-base kernels are shorter than their copies and lose to the per-chunk launch costs, 3.4 ->
+// 4.5 ms; the secret-scalar combs take the chunks, 5.3 -> 4.3 ms).  launch(lo, cnt) enqueues the kernels of units
+// lo .. lo + cnt on ctx->stream and returns an ECCX code.
+template <class Launch>
+int host_pipeline(eccx_ctx* ctx, size_t n, const HostIn* ins, int nins, const HostOut* outs, int nouts, bool chunked,
+                  Launch launch) {
+  const size_t nchunks = (chunked && n >= ((size_t)1 << 17)) ? 4 : 1;
   static_assert(2 * 4 <= eccx_ctx::NEV, "two events per chunk");
   const size_t step = ((n + nchunks - 1) / nchunks + 4095) / 4096 * 4096;
   // a single chunk keeps everything on the compute stream (crossing streams costs ~1 ms of idle gaps)
@@ -502,14 +492,18 @@ int run_host(eccx_ctx* ctx, int curve, bool base, size_t n, const uint8_t* scala
   size_t prev_lo = 0, prev_cnt = 0;
   auto copy_out = [&](size_t lo, size_t cnt, hipEvent_t done) -> hipError_t {
     hipError_t r = s_out == ctx->stream ? hipSuccess : hipStreamWaitEvent(s_out, done, 0);
-    if (r == hipSuccess) r = hipMemcpyAsync(out + lo * pb, d_o + lo * pb, cnt * pb, hipMemcpyDeviceToHost, s_out);
-    if (r == hipSuccess) r = hipMemcpyAsync(flags + lo, d_f + lo, cnt, hipMemcpyDeviceToHost, s_out);
+    for (int o = 0; o < nouts && r == hipSuccess; ++o)
+      if (outs[o].host)
+        r = hipMemcpyAsync(outs[o].host + lo * outs[o].width, outs[o].dev + lo * outs[o].width, cnt * outs[o].width,
+                           hipMemcpyDeviceToHost, s_out);
     return r;
   };
   for (size_t lo = 0; lo < n; lo += step) {
     const size_t cnt = std::min(step, n - lo);
-    TRY2_(hipMemcpyAsync(d_k + lo * sb, scalars + lo * sb, cnt * sb, hipMemcpyHostToDevice, s_in));
-    if (!base) TRY2_(hipMemcpyAsync(d_p + lo * pb, points + lo * pb, cnt * pb, hipMemcpyHostToDevice, s_in));
+    for (int i = 0; i < nins; ++i)
+      if (ins[i].host)
+        TRY2_(hipMemcpyAsync(ins[i].dev + lo * ins[i].width, ins[i].host + lo * ins[i].width, cnt * ins[i].width,
+                             hipMemcpyHostToDevice, s_in));
     hipEvent_t done = nullptr;
     if (nchunks > 1) {
       hipEvent_t in_ready = ctx->evs[next_ev++];
@@ -517,8 +511,7 @@ int run_host(eccx_ctx* ctx, int curve, bool base, size_t n, const uint8_t* scala
       TRY2_(hipEventRecord(in_ready, s_in));
       TRY2_(hipStreamWaitEvent(ctx->stream, in_ready, 0));
     }
-    if (base) rc = eccx_scalarmul_base_dev(ctx, curve, cnt, d_k + lo * sb, d_o + lo * pb, d_f + lo, d_j, opts, ctx->stream);
-    else rc = eccx_scalarmul_var_dev(ctx, curve, cnt, d_k + lo * sb, d_p + lo * pb, d_o + lo * pb, d_f + lo, d_j, opts, ctx->stream);
+    const int rc = launch(lo, cnt);
     if (rc) { settle(); return rc; }
     if (nchunks > 1) {
       TRY2_(hipEventRecord(done, ctx->stream));
@@ -527,11 +520,37 @@ int run_host(eccx_ctx* ctx, int curve, bool base, size_t n, const uint8_t* scala
     prev_done = done; prev_lo = lo; prev_cnt = cnt;
   }
   TRY2_(copy_out(prev_lo, prev_cnt, prev_done));
-  if (proj) TRY2_(hipMemcpyAsync(proj, d_j, n * proj_bytes(ops), hipMemcpyDeviceToHost, s_out));  // single chunk: same stream
   TRY2_(hipStreamSynchronize(s_out));
   if (s_out != ctx->stream) TRY2_(hipStreamSynchronize(ctx->stream));
 #undef TRY2_
   return ECCX_OK;
+}
+
+// host-buffer wrapper shared by var / base
+int run_host(eccx_ctx* ctx, int curve, bool base, size_t n, const uint8_t* scalars, const uint8_t* points,
+             uint8_t* out, uint8_t* flags, uint8_t* proj, uint32_t opts) {
+  const CurveOps* ops = ops_of(curve);
+  if (!ctx) return ECCX_ERR_ARG;
+  if (!ops) return curve_err(ctx);
+  if (n == 0) return ECCX_OK;
+  if (!scalars || !out || !flags || (!base && !points)) return arg_err(ctx, "null buffer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  size_t sb = ops->info.sb, pb = 2 * (size_t)ops->info.fb;
+  uint8_t *d_k = nullptr, *d_p = nullptr, *d_o = nullptr, *d_f = nullptr, *d_j = nullptr;
+  int rc = ensure_io(ctx, IO_K, n * sb, &d_k);
+  if (!rc) rc = ensure_io(ctx, IO_O, n * pb, &d_o);
+  if (!rc) rc = ensure_io(ctx, IO_F, n, &d_f);
+  if (!rc && !base) rc = ensure_io(ctx, IO_P, n * pb, &d_p);
+  if (!rc && proj) rc = ensure_io(ctx, IO_J, n * proj_bytes(ops), &d_j);
+  if (rc) return rc;
+  // in chunks where the kernels outlast the copies (host_pipeline); proj (the mirror kernels' X:Y:Z) in one piece
+  const bool chunked = !proj && (!base || ((opts & ECCX_CT_SCAN) && !(opts & (ECCX_MIRROR_REFERENCE | ECCX_TABLE_IN_L2))));
+  const HostIn ins[2] = {{d_k, scalars, sb}, {d_p, base ? nullptr : points, pb}};
+  const HostOut outs[3] = {{out, d_o, pb}, {flags, d_f, 1}, {proj, d_j, proj_bytes(ops)}};
+  return host_pipeline(ctx, n, ins, 2, outs, 3, chunked, [&](size_t lo, size_t cnt) {
+    if (base) return eccx_scalarmul_base_dev(ctx, curve, cnt, d_k + lo * sb, d_o + lo * pb, d_f + lo, d_j, opts, ctx->stream);
+    return eccx_scalarmul_var_dev(ctx, curve, cnt, d_k + lo * sb, d_p + lo * pb, d_o + lo * pb, d_f + lo, d_j, opts, ctx->stream);
+  });
 }
 
 int run_sharded(eccx_ctx** ctxs, int nctx, int curve, bool base, size_t n, const uint8_t* scalars,
@@ -1052,15 +1071,13 @@ int eccx_double_scalarmul(eccx_ctx* ctx, int curve, size_t n, const uint8_t* u1,
   if (!rc) rc = ensure_io(ctx, IO_O, n * pb, &d_o);
   if (!rc) rc = ensure_io(ctx, IO_F, n, &d_f);
   if (rc) return rc;
-  HIP_TRY(ctx, hipMemcpyAsync(d_u1, u1, n * sb, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(d_u2, u2, n * sb, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(d_q, q, n * pb, hipMemcpyHostToDevice, ctx->stream));
-  rc = eccx_double_scalarmul_dev(ctx, curve, n, d_u1, d_u2, d_q, d_o, d_f, opts, ctx->stream);
-  if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
-  HIP_TRY(ctx, hipMemcpyAsync(out, d_o, n * ((opts & ECCX_OUT_X_ONLY) ? pb / 2 : pb), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(flags, d_f, n, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  return ECCX_OK;
+  const size_t ob = (opts & ECCX_OUT_X_ONLY) ? pb / 2 : pb;
+  const HostIn ins[3] = {{d_u1, u1, sb}, {d_u2, u2, sb}, {d_q, q, pb}};
+  const HostOut outs[2] = {{out, d_o, ob}, {flags, d_f, 1}};
+  return host_pipeline(ctx, n, ins, 3, outs, 2, /*chunked=*/true, [&](size_t lo, size_t cnt) {
+    return eccx_double_scalarmul_dev(ctx, curve, cnt, d_u1 + lo * sb, d_u2 + lo * sb, d_q + lo * pb, d_o + lo * ob, d_f + lo, opts,
+                                     ctx->stream);
+  });
 }
 
 int eccx_x25519_dev(eccx_ctx* ctx, size_t n, const void* d_scalars, const void* d_u, void* d_out, void* d_flags,
@@ -1096,14 +1113,11 @@ int eccx_x25519(eccx_ctx* ctx, size_t n, const uint8_t* scalars, const uint8_t* 
   if (!rc) rc = ensure_io(ctx, IO_F, n, &d_f);
   if (!rc && u) rc = ensure_io(ctx, IO_P, n * 32, &d_u);
   if (rc) return rc;
-  HIP_TRY(ctx, hipMemcpyAsync(d_k, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
-  if (u) HIP_TRY(ctx, hipMemcpyAsync(d_u, u, n * 32, hipMemcpyHostToDevice, ctx->stream));
-  rc = eccx_x25519_dev(ctx, n, d_k, d_u, d_o, d_f, opts, ctx->stream);
-  if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
-  HIP_TRY(ctx, hipMemcpyAsync(out, d_o, n * 32, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(flags, d_f, n, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  return ECCX_OK;
+  const HostIn ins[2] = {{d_k, scalars, 32}, {d_u, u, 32}};
+  const HostOut outs[2] = {{out, d_o, 32}, {flags, d_f, 1}};
+  return host_pipeline(ctx, n, ins, 2, outs, 2, /*chunked=*/true, [&](size_t lo, size_t cnt) {
+    return eccx_x25519_dev(ctx, cnt, d_k + lo * 32, d_u ? d_u + lo * 32 : nullptr, d_o + lo * 32, d_f + lo, opts, ctx->stream);
+  });
 }
 
 int eccx_comb_table(eccx_ctx* ctx, int curve, uint8_t* out) {
