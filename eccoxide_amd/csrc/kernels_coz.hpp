@@ -382,7 +382,7 @@ __global__ void __launch_bounds__(WG, (coz_occupancy<CU, GLV>())) k_scalarmul_co
       d[2] = make_uint4(k2[0], k2[1], k2[2], k2[3]);
       d[3] = make_uint4(k2[4], 0u, 0u, 0u);
     }
-    const uint32_t* __restrict__ kw = row(0);
+    const uint32_t* kw = row(0);  // written above through another pointer: no restrict
 
     T one;
 #pragma unroll
@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(WG, (coz_occupancy<CU, GLV>())) k_scalarmul_co
     auto booth = [&](int w, bool second, uint32_t& d, bool& neg) {
       uint32_t w6;
       if constexpr (GLV) {
-        const uint32_t* __restrict__ h = kw + (second ? 8 : 0);
+        const uint32_t* h = kw + (second ? 8 : 0);
         const int pos = WB * w - 1 + 32;  // one zero word below the scalar
         const int wi = pos >> 5, sh = pos & 31;
         const uint32_t lo = (wi >= 1 && wi <= 5) ? h[wi - 1] : 0u;
