@@ -105,6 +105,22 @@ def branch_census(body):
     rows = []
     block = "<entry>"
     last = {"scc": "-", "vcc": "-", "exec": "-"}
+    sgpr_def = {}  # "s[4:5]" / "s7" -> the instruction that last wrote it (textually: a hint, not a dataflow analysis)
+
+    def trace(producer, depth=2):
+        """follow the SGPR operands of a mask-combining producer (s_and_b64 vcc, exec, s[4:5]; s_and_saveexec_b64 ...)
+        to the instructions that last wrote them, so that the census shows the comparison behind the mask"""
+        out = producer
+        if depth == 0 or producer == "-":
+            return out
+        ops = producer.split(None, 1)
+        if len(ops) < 2 or not ops[0].startswith(("s_and", "s_or", "s_xor", "s_nor", "s_nand", "s_cselect", "s_mov", "s_not")):
+            return out
+        srcs = [a.strip() for a in ops[1].split(",")][1:]
+        for src in srcs:
+            if re.fullmatch(r"s\d+|s\[\d+:\d+\]", src) and src in sgpr_def:
+                out += f"   [{src} <- {trace(sgpr_def[src], depth - 1)}]"
+        return out
     for line in body:
         m = re.match(r"^(\.LBB\w+):", line)
         if m:
@@ -120,8 +136,12 @@ def branch_census(body):
             uniformisers[op] += 1
         if op.startswith("s_cbranch"):
             reg = "scc" if "scc" in op else ("vcc" if "vcc" in op else ("exec" if "exec" in op else "?"))
-            rows.append((block, op, args, last.get(reg, "-")))
+            rows.append((block, op, args, trace(last.get(reg, "-"))))
             continue
+        dst = args.split(",")[0].strip() if args else ""
+        if re.fullmatch(r"s\d+|s\[\d+:\d+\]", dst) and not op.startswith(("s_cmp", "s_bitcmp", "s_waitcnt", "s_nop")):
+            # for the instructions that write scc as a side effect the defining compare matters more than the op itself
+            sgpr_def[dst] = f"{op} {args}" + (f" (scc <- {last['scc']})" if op.startswith("s_cselect") else "")
         if op.startswith("s_cmp") or op.startswith("s_bitcmp") or (op.startswith("s_") and not op.startswith(("s_mov", "s_load", "s_waitcnt", "s_nop", "s_branch", "s_barrier", "s_cbranch")) and not op.startswith("s_cmp")):
             # most SALU arithmetic writes scc as a side effect; remember the last one
             last["scc"] = f"{op} {args}"
