@@ -147,13 +147,19 @@ ECCX_DEV void u2_load(U<CU, 1, 3>& x, U<CU, 1, 3>& y, const uint32_t* __restrict
 // the two coordinates of a table entry as a row of their own (the secret-scalar ladder's compact table)
 template <class CU>
 constexpr int urow2_words() { return ((2 * CU::N + 3) / 4) * 4; }
-template <class CU>
+#ifndef ECCX_CT_VAR_PK
+#define ECCX_CT_VAR_PK 0  // 1: the secret-scalar ladders scan their table two words per instruction (kernels_ct.hpp ct_fsel2) --
+                          // measured 0.5-1.7 % SLOWER than v_cndmask here (the rows come from HBM, not LDS; the pairs cost registers): off
+#endif
+// TAGGED: every word | CT_F32_TAG, the form the two-word select reads (limbs stay below 3 * 2^28: see ct_scan_lds_pk)
+template <class CU, bool TAGGED = false>
 ECCX_DEV void u2_store(uint32_t* __restrict__ row, const U<CU, 1, 3>& x, const U<CU, 1, 3>& y) {
   constexpr int N = CU::N;
   constexpr int W = urow2_words<CU>();
+  constexpr uint32_t T = TAGGED ? CT_F32_TAG : 0u;
   uint32_t w[W];
 #pragma unroll
-  for (int i = 0; i < W; ++i) w[i] = i < N ? x.v[i] : (i < 2 * N ? y.v[i - N] : 0u);
+  for (int i = 0; i < W; ++i) w[i] = (i < N ? x.v[i] : (i < 2 * N ? y.v[i - N] : 0u)) | T;
   uint4* dst = reinterpret_cast<uint4*>(row);
 #pragma unroll
   for (int i = 0; i < W / 4; ++i) dst[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
@@ -456,7 +462,7 @@ __global__ void __launch_bounds__(WG, (coz_occupancy<CU, GLV>())) k_scalarmul_co
       // ---- common denominator zeta = Z_TBL ----
       T lam = one, next = ratio;
       if constexpr (ISO) {
-        if constexpr (CT) u2_store<CU>(crow(TBL), tx, ty);  // the top entry is affine on E' as it stands
+        if constexpr (CT) u2_store<CU, (ECCX_CT_VAR_PK != 0)>(crow(TBL), tx, ty);  // the top entry is affine on E' as it stands
         else if constexpr (GLV) u3_store<CU>(row(TBL), tx, ty, u_fit<1, 3>(u_mul_k<CU>(tx, CU::BETA)));
       } else {
         // 1 / zeta (zeta = 0 only for degenerate units, which are redone anyway: the inverse of 0 is 0)
@@ -467,7 +473,7 @@ __global__ void __launch_bounds__(WG, (coz_occupancy<CU, GLV>())) k_scalarmul_co
         const T l2 = u_fit<1, 3>(u_sqr(lam));
         const T l3 = u_fit<1, 3>(u_mul(l2, lam));
         const T xt = u_fit<1, 3>(u_mul(tx, l2)), yt = u_fit<1, 3>(u_mul(ty, l3));
-        if constexpr (CT) u2_store<CU>(crow(TBL), xt, yt);
+        if constexpr (CT) u2_store<CU, (ECCX_CT_VAR_PK != 0)>(crow(TBL), xt, yt);
         else u3_store<CU>(row(TBL), xt, yt, one);
       }
       for (int d = TBL - 1; d >= 1; --d) {
@@ -478,7 +484,7 @@ __global__ void __launch_bounds__(WG, (coz_occupancy<CU, GLV>())) k_scalarmul_co
         const T l3 = u_fit<1, 3>(u_mul(l2, lam));
         const T xs = u_fit<1, 3>(u_mul(x, l2));
         const T ys = u_fit<1, 3>(u_mul(y, l3));
-        if constexpr (CT) u2_store<CU>(crow(d), xs, ys);
+        if constexpr (CT) u2_store<CU, (ECCX_CT_VAR_PK != 0)>(crow(d), xs, ys);
         else if constexpr (GLV) u3_store<CU>(row(d), xs, ys, u_fit<1, 3>(u_mul_k<CU>(xs, CU::BETA)));
         else u3_store<CU>(row(d), xs, ys, one);
       }
@@ -502,6 +508,34 @@ __global__ void __launch_bounds__(WG, (coz_occupancy<CU, GLV>())) k_scalarmul_co
         bool neg;
         booth(w, second, d, neg);
         neg = neg != second;  // `second` is the same for every lane
+#if ECCX_CT_VAR_PK
+        {
+          // two words per select: the rows hold tagged limbs (exact under v_pk_fma_f32 against 1.0 / 0.0, kernels_ct.hpp)
+          uint64_t acc[N];  // 2N words
+#pragma unroll
+          for (int p = 0; p < N; ++p) acc[p] = 0;
+#pragma unroll 2
+          for (int j = 1; j <= TBL; ++j) {
+            uint32_t m;
+            asm("v_cndmask_b32_e64 %0, 0, 1.0, %1" : "=v"(m) : "s"(__builtin_amdgcn_uicmp(d, (uint32_t)j, 32 /* ICMP_EQ */)));
+            const uint64_t m2 = m;
+            const uint4* src = reinterpret_cast<const uint4*>(crow(j));
+            uint4 v[WC / 4];
+#pragma unroll
+            for (int c = 0; c < WC / 4; ++c) v[c] = src[c];
+#pragma unroll
+            for (int p = 0; p < N; ++p) {
+              const uint4 qv = v[p / 2];
+              ct_fsel2(acc[p], (p & 1) ? (((uint64_t)qv.w << 32) | qv.z) : (((uint64_t)qv.y << 32) | qv.x), m2);
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < N; ++i) {
+            ex.v[i] = (uint32_t)(acc[i / 2] >> (32 * (i & 1))) & ~CT_F32_TAG;
+            ey.v[i] = (uint32_t)(acc[(N + i) / 2] >> (32 * ((N + i) & 1))) & ~CT_F32_TAG;
+          }
+        }
+#else
         u_set_zero(ex);
         u_set_zero(ey);
 #pragma unroll 2
@@ -512,6 +546,7 @@ __global__ void __launch_bounds__(WG, (coz_occupancy<CU, GLV>())) k_scalarmul_co
           u_cmov_ct(ex, m, cx);
           u_cmov_ct(ey, m, cy);
         }
+#endif
         if constexpr (GLV) {
           if (second) ex = u_fit<1, 3>(u_mul_k<CU>(ex, CU::BETA));
         }
